@@ -1,0 +1,80 @@
+/*
+ * fp_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's uniformly partitioned convolution
+ * path (Flixor/IRBaboon), used ONLY by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg as the checker / CPU baseline.  Nothing under
+ * irbaboon_amd/ or include/ may include, link or call this.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors or tests
+ *  and cannot be compiled in this image (it needs the
+ * un-vendored JUCE 6.0.1 and Boost 1.69 headers).  The restatement is pinned
+ * only by (a) the reference's own known-answer constant, IRpulse = unit
+ * delta at sample 100 (Source/PluginProcessor.cpp:46) => pure delay, and
+ * (b) float64 direct convolution, the mathematical definition of what
+ * fp::convolution::convolvePeriodic computes.  The FFT butterflies live in
+ * the third-party juce::dsp::FFT (module juce_dsp, JUCE 6.0.1, not in
+ * /root/reference); fp_fft_* restates the published algorithm of its
+ * portable fallback engine (kissfft-style radix-4/2 decimation in time,
+ * twiddles computed in double and stored as float, inverse scaled by 1/N).
+ *
+ * Every function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ */
+#ifndef FP_ORACLE_H
+#define FP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- juce::dsp::FFT stand-in (call sites fp/convolution.cpp:75-77,123,144,206) ---- */
+typedef struct fp_fft fp_fft;
+fp_fft *fp_fft_create(int order);            /* N = 1 << order                       */
+void    fp_fft_destroy(fp_fft *f);
+int     fp_fft_size(const fp_fft *f);
+/* d holds 2N floats; reads d[0..N) real, writes N interleaved complex bins (bins
+ * above N/2 are the conjugate mirror, as the fallback engine leaves them). */
+void    fp_fft_forward_real(const fp_fft *f, float *d);
+/* consumes bins 0..N/2 of d, writes N real samples to d[0..N) scaled by 1/N.      */
+void    fp_fft_inverse_real(const fp_fft *f, float *d);
+
+/* ---- fp::tools (fp/tools.cpp:14-30, 44-52) ---- */
+void fp_complexMul(float *a, float *b, float c, float d);
+void fp_sumToMono(float *ch0, float *ch1, int n);
+
+/* ---- fp::convolution::convolvePeriodic (fp/convolution.cpp:14-242) ----
+ * audio: planar [audio_ch][La]; ir: planar [ir_ch][Lh]; out: planar
+ * [audio_ch][La+Lh-1], overwritten.  Returns 0, or -1 for an unknown channel
+ * layout (output cleared, as the reference does at :39-42).
+ * Includes the dropped-tail quirk (:236-238). */
+int fp_convolvePeriodic(const float *const *audio, int audio_ch, int La,
+                        const float *const *ir, int ir_ch, int Lh,
+                        int processBlockSize, float *const *out);
+
+/* ---- fp::convolution::convolveNonPeriodic (fp/convolution.cpp:246-347) ---- */
+int fp_convolveNonPeriodic(const float *const *audio, int audio_ch, int La,
+                           const float *const *ir, int ir_ch, int Lh,
+                           float *const *out);
+
+/* ---- IRBaboonAudioProcessor convolution state (Source/PluginProcessor.cpp
+ *      ctor :57-82, prepareToPlay :164-234, processBlock IDLE branch :408-562,
+ *      rings per fp/CircularBufferArray.cpp:94-128) ----
+ * channels = generalInputAudioChannels (2 in the plug-in), block = processBlockSize
+ * (256), ir_ring_len = IRpulse length (2048) that fixes irPartitions (:225).
+ * The IR fed to the rolling refresh (:455-461) is set with fp_rt_set_ir; it must
+ * hold at least irPartitions*block samples (the reference does not check, :457). */
+typedef struct fp_rt fp_rt;
+fp_rt *fp_rt_create(int channels, int block, int ir_ring_len);
+void   fp_rt_destroy(fp_rt *p);
+void   fp_rt_prepareToPlay(fp_rt *p, int samplesPerBlock);
+void   fp_rt_set_ir(fp_rt *p, const float *ir, int len);
+/* in-place on planar buffer[channels][n]; convolution part only (no gain/limiter). */
+void   fp_rt_processBlock(fp_rt *p, float *const *buffer, int n);
+int    fp_rt_latency(const fp_rt *p);
+int    fp_rt_partitions(const fp_rt *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+"""ctypes binding of the CPU oracle (oracle/libfp_oracle.so).  Test infrastructure:
+imported only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libfp_oracle.so")
+
+_fpp = C.POINTER(C.POINTER(C.c_float))
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.fp_convolvePeriodic.restype = C.c_int
+    lib.fp_convolvePeriodic.argtypes = [_fpp, C.c_int, C.c_int, _fpp, C.c_int, C.c_int, C.c_int, _fpp]
+    lib.fp_convolveNonPeriodic.restype = C.c_int
+    lib.fp_convolveNonPeriodic.argtypes = [_fpp, C.c_int, C.c_int, _fpp, C.c_int, C.c_int, _fpp]
+    lib.fp_fft_create.restype = C.c_void_p
+    lib.fp_fft_create.argtypes = [C.c_int]
+    lib.fp_fft_destroy.argtypes = [C.c_void_p]
+    lib.fp_fft_forward_real.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.fp_fft_inverse_real.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.fp_rt_create.restype = C.c_void_p
+    lib.fp_rt_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.fp_rt_destroy.argtypes = [C.c_void_p]
+    lib.fp_rt_prepareToPlay.argtypes = [C.c_void_p, C.c_int]
+    lib.fp_rt_set_ir.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    lib.fp_rt_processBlock.argtypes = [C.c_void_p, _fpp, C.c_int]
+    lib.fp_rt_latency.restype = C.c_int
+    lib.fp_rt_latency.argtypes = [C.c_void_p]
+    lib.fp_rt_partitions.restype = C.c_int
+    lib.fp_rt_partitions.argtypes = [C.c_void_p]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _planar(a):
+    a = np.ascontiguousarray(np.atleast_2d(a), dtype=np.float32)
+    ptrs = (C.POINTER(C.c_float) * a.shape[0])(*[a[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(a.shape[0])])
+    return a, ptrs
+
+
+def convolve_periodic(audio, ir, block=256):
+    """fp::convolution::convolvePeriodic (fp/convolution.cpp:14-242) on planar
+    float32 arrays [channels][samples]; returns [audio_ch][La+Lh-1]."""
+    a, ap = _planar(audio)
+    h, hp = _planar(ir)
+    out = np.zeros((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
+    _, op = _planar(out)
+    # _planar copies only if needed; out is already contiguous float32, so op aliases it
+    op = (C.POINTER(C.c_float) * out.shape[0])(*[out[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(out.shape[0])])
+    rc = lib().fp_convolvePeriodic(ap, a.shape[0], a.shape[1], hp, h.shape[0], h.shape[1], block, op)
+    return out, rc
+
+
+def convolve_nonperiodic(audio, ir):
+    a, ap = _planar(audio)
+    h, hp = _planar(ir)
+    out = np.zeros((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
+    op = (C.POINTER(C.c_float) * out.shape[0])(*[out[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(out.shape[0])])
+    rc = lib().fp_convolveNonPeriodic(ap, a.shape[0], a.shape[1], hp, h.shape[0], h.shape[1], op)
+    return out, rc
+
+
+def rfft(x, order):
+    """performRealOnlyForwardTransform: returns complex bins 0..N/2."""
+    n = 1 << order
+    d = np.zeros(2 * n, np.float32)
+    d[:n] = x
+    f = lib().fp_fft_create(order)
+    lib().fp_fft_forward_real(f, d.ctypes.data_as(C.POINTER(C.c_float)))
+    lib().fp_fft_destroy(f)
+    return d[0:n + 2:2] + 1j * d[1:n + 2:2]
+
+
+def irfft(X, order):
+    n = 1 << order
+    d = np.zeros(2 * n, np.float32)
+    d[0:n + 2:2] = X.real
+    d[1:n + 2:2] = X.imag
+    f = lib().fp_fft_create(order)
+    lib().fp_fft_inverse_real(f, d.ctypes.data_as(C.POINTER(C.c_float)))
+    lib().fp_fft_destroy(f)
+    return d[:n].copy()
+
+
+class RtProcessor:
+    """IRBaboonAudioProcessor's convolution state machine
+    (Source/PluginProcessor.cpp:57-82,164-234,408-562)."""
+
+    def __init__(self, channels=2, block=256, ir_ring_len=2048):
+        self.p = lib().fp_rt_create(channels, block, ir_ring_len)
+        self.channels = channels
+
+    def prepare_to_play(self, samples_per_block):
+        lib().fp_rt_prepareToPlay(self.p, samples_per_block)
+
+    def set_ir(self, ir):
+        ir = np.ascontiguousarray(ir, np.float32)
+        lib().fp_rt_set_ir(self.p, ir.ctypes.data_as(C.POINTER(C.c_float)), len(ir))
+
+    def process_block(self, buf):
+        """buf: float32 [channels][n], processed in place."""
+        assert buf.dtype == np.float32 and buf.flags.c_contiguous and buf.shape[0] == self.channels
+        ptrs = (C.POINTER(C.c_float) * buf.shape[0])(*[buf[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(buf.shape[0])])
+        lib().fp_rt_processBlock(self.p, ptrs, buf.shape[1])
+
+    @property
+    def latency(self):
+        return lib().fp_rt_latency(self.p)
+
+    @property
+    def partitions(self):
+        return lib().fp_rt_partitions(self.p)
+
+    def __del__(self):
+        try:
+            lib().fp_rt_destroy(self.p)
+        except Exception:
+            pass
