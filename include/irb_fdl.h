@@ -1,0 +1,164 @@
+/*
+ * irb_fdl.h -- C ABI of the MI355X partitioned-convolution engine (libirbfdl.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of Flixor/IRBaboon that this
+ * repository accelerates: uniformly partitioned overlap-add FFT convolution with
+ * a frequency-domain delay line (FDL).  The reference has no FFI for it -- the
+ * path is a C++ free function and a block of code inlined in the plug-in's audio
+ * callback -- so each entry point below names the reference code it replaces
+ * (paths relative to the reference checkout).  Plain pointers and sizes only; no
+ * C++/torch/JUCE types cross this boundary.
+ *
+ * Vocabulary (as in the reference): "block" = processBlockSize samples (B),
+ * "partition" = one B-sample slice of the impulse response (IR), N = FFT length
+ * (smallest power of two >= 2B-1, fp/convolution.cpp:45-48), P = ceil(Lh/B)
+ * partitions (fp/convolution.cpp:52), "instance" = one independent plug-in /
+ * IR x stream pair, "stream" = one (instance, channel) convolution.
+ *
+ * Threading: one caller thread per handle ("the audio thread").  After create
+ * no entry point allocates device memory.  The *_device entry points enqueue
+ * work on the handle's HIP stream and return without waiting.
+ *
+ * Errors: every int-returning function gives IRB_OK (0) or a negative code, and
+ * irb_last_error() (thread local) describes the last failure.  The reference's
+ * own convention -- DBG() and a cleared output buffer
+ * (fp/convolution.cpp:39-42) -- is kept by irb_convolve_periodic, which clears
+ * `out` before it reports IRB_ERR_LAYOUT.
+ */
+#ifndef IRB_FDL_H
+#define IRB_FDL_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRB_OK            0
+#define IRB_ERR_ARG      (-1)   /* bad argument / size                              */
+#define IRB_ERR_HIP      (-2)   /* HIP runtime failure (no GPU, OOM, launch error)  */
+#define IRB_ERR_LAYOUT   (-3)   /* channel layout outside mono/stereo x mono/stereo */
+#define IRB_ERR_STATE    (-4)   /* call not legal in this state                     */
+
+/* irb_fdl_config.flags */
+#define IRB_FDL_FORCE_FUSED   0x1u  /* always one workgroup per stream               */
+#define IRB_FDL_FORCE_SPLIT   0x2u  /* always split the partitions over workgroups   */
+
+typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
+typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */
+
+typedef struct irb_fdl_config {
+    int   device;               /* HIP device ordinal                                 */
+    int   n_instances;          /* independent instances batched on this device       */
+    int   channels;             /* audio channels per instance (reference: 1 or 2)    */
+    int   block;                /* B, processBlockSize (Source/PluginProcessor.h:197) */
+    int   max_ir_len;           /* longest IR in samples; fixes P                     */
+    int   max_blocks_per_call;  /* most blocks one process call may carry (>= 1)      */
+    void *stream;               /* hipStream_t to enqueue on; NULL: own stream        */
+    unsigned flags;
+} irb_fdl_config;
+
+typedef struct irb_fdl_info {
+    int    fft_len;             /* N                                                  */
+    int    partitions;          /* P                                                  */
+    int    ring_slots;          /* FDL ring length (>= P)                             */
+    int    streams;             /* n_instances * channels                             */
+    int    splits;              /* workgroups per stream in the MAC kernel (1=fused)  */
+    size_t device_bytes;        /* HBM held by this handle                            */
+    double algorithmic_bytes_per_block_step;   /* per stream: 8*P*N + 16*B */
+} irb_fdl_info;
+
+/* Replaces: plug-in ctor + prepareToPlay ring/FFT set-up
+ * (Source/PluginProcessor.cpp:57-82, 203-233) and the buffer allocation of
+ * convolvePeriodic (fp/convolution.cpp:45-87).  FDL and overlap start cleared. */
+int  irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out);
+
+/* Replaces: releaseResources / dtor (Source/PluginProcessor.cpp:240-248, 89-96). */
+void irb_fdl_destroy(irb_fdl *h);
+
+int  irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info);
+
+/* Replaces: IR partitioning + forward FFT (fp/convolution.cpp:106-125) including
+ * the channel-layout rules (fp/convolution.cpp:28-42, 94-101, 120-121, 176-181):
+ *   ir_channels 1            -> every audio channel of `instance` uses ir[0]
+ *   ir_channels 2, channels 2 -> audio channel c uses ir[c]
+ *   ir_channels 2, channels 1 -> (ir[0]+ir[1])/2 (tools::sumToMono, fp/tools.cpp:14-30)
+ * ir: host pointers, planar [ir_channels][len], len <= max_ir_len.  Takes effect
+ * for all partitions at once (the whole-IR behaviour of convolvePeriodic).      */
+int  irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_channels, int len);
+
+/* Replaces: the rolling one-partition-per-block refresh of the real-time path
+ * (Source/PluginProcessor.cpp:455-461): re-derives partition `partition` of
+ * every stream of `instance` from `block` host samples (IR channel 0 feeds both
+ * audio channels there, :485).                                                   */
+int  irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const float *samples);
+
+/* Zero the FDL and the overlap (what a fresh convolvePeriodic call starts from,
+ * fp/convolution.cpp:59,67,81,87).  IR spectra are kept.                         */
+int  irb_fdl_reset(irb_fdl *h);
+
+/* Replaces: one or more FDL steps -- forward FFT of the new block into the ring
+ * (fp/convolution.cpp:128-145; RT Source/PluginProcessor.cpp:428-444), the
+ * multiply-accumulate over partitions (fp/convolution.cpp:171-202; RT :480-501),
+ * inverse FFT (:206; RT :504) and overlap-add (:209-213; RT :506-510).
+ * in/out: host pointers, planar, one per stream (stream = instance*channels+ch),
+ * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.     */
+int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
+
+/* Same with device-resident audio: stream s, block j lives at
+ * d_in + s*stride + j*block (floats); likewise d_out.  Asynchronous.            */
+int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks);
+
+int  irb_fdl_synchronize(irb_fdl *h);
+
+/* Stream-ordered timing on the handle's stream (hipEvent): `mark` records event
+ * slot 0 or 1; `elapsed_ms` waits for both and returns slot1 - slot0.            */
+int  irb_fdl_mark(irb_fdl *h, int slot);
+int  irb_fdl_elapsed_ms(irb_fdl *h, float *ms);
+
+/* Device scratch owned by the handle, for callers that want device-resident
+ * audio without another allocator: [streams][max_blocks_per_call*block] floats
+ * each.  Pointers stay valid until destroy.                                      */
+int  irb_fdl_device_io(irb_fdl *h, float **d_in, float **d_out, long *stride);
+int  irb_fdl_upload(irb_fdl *h, float *d_dst, const float *src, size_t n_floats);
+int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_floats);
+
+/* Replaces: AudioBuffer<float> fp::convolution::convolvePeriodic(AudioBuffer<float>&
+ * audio, AudioBuffer<float>& ir, int processBlockSize) (fp/convolution.hpp:31,
+ * fp/convolution.cpp:14-242), whole signal in, whole signal out.
+ * audio: planar [audio_ch][La]; ir: planar [ir_ch][Lh]; out: planar
+ * [audio_ch][La+Lh-1].  keep_reference_tail != 0 reproduces the reference's
+ * dropped tail (only (floor(La/B)+P)*B samples are written, the rest stay 0,
+ * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.        */
+int  irb_convolve_periodic(int device,
+                           const float *const *audio, int audio_ch, int La,
+                           const float *const *ir, int ir_ch, int Lh,
+                           int processBlockSize, int keep_reference_tail,
+                           float *const *out);
+
+/* ---- processBlock-shaped adapter ---------------------------------------------
+ * Replaces the IRCAP_IDLE branch of IRBaboonAudioProcessor::processBlock
+ * (Source/PluginProcessor.cpp:408-562) with its set-up in the ctor (:57-82) and
+ * prepareToPlay (:164-234): host-block <-> 256 re-blocking (:421-445, :525-560),
+ * latency max(hostBlock, block) (:169-174), IR channel 0 for every audio channel
+ * (:485), irPartitions fixed by ir_ring_len (:225), and the rolling
+ * one-partition-per-block IR refresh (:455-461).  Output gain and the limiter
+ * (:567-574) stay in the plug-in.  Default IR: unit delta at sample 100 (:46).   */
+int  irb_rt_create(int device, int channels, int block, int ir_ring_len, irb_rt **out);
+void irb_rt_destroy(irb_rt *p);
+int  irb_rt_prepare_to_play(irb_rt *p, int samples_per_block);
+int  irb_rt_release_resources(irb_rt *p);
+/* IRtoConvolve (:411-414): host samples, copied; must hold >= partitions*block.  */
+int  irb_rt_set_ir(irb_rt *p, const float *ir, int len);
+/* buffer: planar host [channels][n], processed in place.                         */
+int  irb_rt_process_block(irb_rt *p, float *const *buffer, int n);
+int  irb_rt_latency(const irb_rt *p);
+int  irb_rt_partitions(const irb_rt *p);
+
+const char *irb_last_error(void);
+const char *irb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

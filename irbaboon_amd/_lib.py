@@ -1,0 +1,93 @@
+"""ctypes loader for libirbfdl.so (the C ABI of include/irb_fdl.h).
+
+The library is built in-tree by `make -C irbaboon_amd/csrc` (see __graft_entry__.build).
+There is no Python or CPU fallback: if the shared object is missing or a HIP device
+is absent, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libirbfdl.so")
+
+IRB_OK, IRB_ERR_ARG, IRB_ERR_HIP, IRB_ERR_LAYOUT, IRB_ERR_STATE = 0, -1, -2, -3, -4
+FORCE_FUSED, FORCE_SPLIT = 0x1, 0x2
+
+fpp = C.POINTER(C.POINTER(C.c_float))
+fp = C.POINTER(C.c_float)
+
+
+class IrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"irb error {code}: {msg}")
+        self.code = code
+
+
+class FdlConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("n_instances", C.c_int), ("channels", C.c_int), ("block", C.c_int),
+                ("max_ir_len", C.c_int), ("max_blocks_per_call", C.c_int), ("stream", C.c_void_p),
+                ("flags", C.c_uint)]
+
+
+class FdlInfo(C.Structure):
+    _fields_ = [("fft_len", C.c_int), ("partitions", C.c_int), ("ring_slots", C.c_int), ("streams", C.c_int),
+                ("splits", C.c_int), ("device_bytes", C.c_size_t),
+                ("algorithmic_bytes_per_block_step", C.c_double)]
+
+
+# every symbol include/irb_fdl.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("irb_fdl_create", C.c_int, [C.POINTER(FdlConfig), C.POINTER(C.c_void_p)]),
+    ("irb_fdl_destroy", None, [C.c_void_p]),
+    ("irb_fdl_get_info", C.c_int, [C.c_void_p, C.POINTER(FdlInfo)]),
+    ("irb_fdl_set_ir", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
+    ("irb_fdl_set_ir_partition", C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    ("irb_fdl_reset", C.c_int, [C.c_void_p]),
+    ("irb_fdl_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
+    ("irb_fdl_process_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
+    ("irb_fdl_synchronize", C.c_int, [C.c_void_p]),
+    ("irb_fdl_mark", C.c_int, [C.c_void_p, C.c_int]),
+    ("irb_fdl_elapsed_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("irb_fdl_device_io", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
+    ("irb_fdl_upload", C.c_int, [C.c_void_p, C.c_void_p, fp, C.c_size_t]),
+    ("irb_fdl_download", C.c_int, [C.c_void_p, fp, C.c_void_p, C.c_size_t]),
+    ("irb_convolve_periodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, C.c_int, C.c_int, fpp]),
+    ("irb_rt_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("irb_rt_destroy", None, [C.c_void_p]),
+    ("irb_rt_prepare_to_play", C.c_int, [C.c_void_p, C.c_int]),
+    ("irb_rt_release_resources", C.c_int, [C.c_void_p]),
+    ("irb_rt_set_ir", C.c_int, [C.c_void_p, fp, C.c_int]),
+    ("irb_rt_process_block", C.c_int, [C.c_void_p, fpp, C.c_int]),
+    ("irb_rt_latency", C.c_int, [C.c_void_p]),
+    ("irb_rt_partitions", C.c_int, [C.c_void_p]),
+    ("irb_last_error", C.c_char_p, []),
+    ("irb_version", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libirbfdl.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(f"{SO_PATH} not built: run `make -C irbaboon_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(SO_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != IRB_OK:
+        raise IrbError(rc, lib().irb_last_error().decode("utf-8", "replace"))
+
+
+def planar_ptrs(a):
+    """float32 C-contiguous [rows][n] -> float** over the rows (the array must outlive the call)."""
+    return (fp * a.shape[0])(*[a[i].ctypes.data_as(fp) for i in range(a.shape[0])])

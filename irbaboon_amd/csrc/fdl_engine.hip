@@ -1,0 +1,468 @@
+// fdl_engine.hip -- host side of libirbfdl.so: the C ABI of include/irb_fdl.h on top of the
+// gfx950 kernels in fdl_kernels.hpp.  Pure HIP runtime + C++17; no torch, no JUCE.
+//
+// There is deliberately NO CPU fallback in this library: every entry point that computes
+// needs a HIP device and reports IRB_ERR_HIP when there is none.
+#include "../../include/irb_fdl.h"
+#include "fdl_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(IRB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int fft_len_for_block(int B)
+{
+    int N = 1;
+    while (N < 2 * B - 1) N *= 2;            // fp/convolution.cpp:45-48
+    return std::max(N, 32);                  // any power of two >= 2B-1 gives the same linear convolution
+}
+
+}  // namespace
+
+struct irb_fdl {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
+    unsigned flags = 0;
+    long long t = 0;                         // block steps done since reset
+    size_t bytes = 0;
+
+    float2 *d_H = nullptr, *d_X = nullptr, *d_tw = nullptr, *d_part = nullptr;
+    float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
+    int *d_set_of_stream = nullptr, *d_np_of_set = nullptr;
+    float *h_io = nullptr;                   // pinned: [S][Tmax*B]
+    float *h_ir = nullptr;                   // pinned: [C][P*B]
+    int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // pinned mirrors
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(irb_fdl *h, T **p, size_t n)
+{
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T)));
+    h->bytes += n * sizeof(T);
+    return IRB_OK;
+}
+
+#define FOR_N(N_, ...)                                                     \
+    switch (N_) {                                                          \
+    case 32:   { constexpr int NN = 32;   __VA_ARGS__; } break;                   \
+    case 64:   { constexpr int NN = 64;   __VA_ARGS__; } break;                   \
+    case 128:  { constexpr int NN = 128;  __VA_ARGS__; } break;                   \
+    case 256:  { constexpr int NN = 256;  __VA_ARGS__; } break;                   \
+    case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break;                   \
+    case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break;                   \
+    case 2048: { constexpr int NN = 2048; __VA_ARGS__; } break;                   \
+    case 4096: { constexpr int NN = 4096; __VA_ARGS__; } break;                   \
+    default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
+    }
+
+int choose_splits(const irb_fdl *h)
+{
+    if (h->flags & IRB_FDL_FORCE_FUSED) return 1;
+    const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
+    const int by_work = (h->P + stripes * 4 - 1) / (stripes * 4);       // >= 4 rows per stripe and workgroup
+    if (h->flags & IRB_FDL_FORCE_SPLIT) return std::max(2, std::min(by_work, 64));
+    if (h->S >= 128) return 1;                                          // enough workgroups already
+    const int by_chip = std::max(1, 768 / h->S);                        // ~3 workgroups per CU
+    const int s = std::min(by_work, by_chip);
+    return s < 2 ? 1 : s;
+}
+
+irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long stride)
+{
+    irb::StepArgs a;
+    a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl; a.tw = h->d_tw;
+    a.set_of_stream = h->d_set_of_stream; a.np_of_set = h->d_np_of_set;
+    a.in = d_in; a.out = d_out; a.part = h->d_part;
+    a.in_stride = stride; a.out_stride = stride;
+    a.B = h->B; a.P = h->P; a.R = h->R; a.head = (int) (h->t % h->R); a.splits = h->splits;
+    return a;
+}
+
+int launch_step(irb_fdl *h, const irb::StepArgs &a)
+{
+    if (h->splits <= 1) {
+        FOR_N(h->N, irb::k_step_fused<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+    } else {
+        FOR_N(h->N, irb::k_push_fft<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+        FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->splits, h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+        FOR_N(h->N, irb::k_reduce_ifft_ola<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+    }
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int first_set, int first_partition)
+{
+    FOR_N(h->N, irb::k_ir_fft<NN><<<dim3(nparts, nrows), dim3(irb::kThreads), 0, h->stream>>>(
+                    d_ir, h->d_H, h->d_tw, h->B, h->P, first_set, first_partition));
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+int upload_maps(irb_fdl *h)
+{
+    HIP_TRY(hipMemcpyAsync(h->d_set_of_stream, h->h_set_of_stream, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_np_of_set, h->h_np_of_set, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
+    return IRB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *irb_last_error(void) { return g_err; }
+int irb_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }   // for rt_adapter.hip
+const char *irb_version(void) { return "irbaboon_amd 0.1 (gfx950)"; }
+
+void irb_fdl_destroy(irb_fdl *h)
+{
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
+    (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
+    (void) hipFree(h->d_set_of_stream); (void) hipFree(h->d_np_of_set);
+    if (h->h_io) (void) hipHostFree(h->h_io);
+    if (h->h_ir) (void) hipHostFree(h->h_ir);
+    if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
+    if (h->h_np_of_set) (void) hipHostFree(h->h_np_of_set);
+    for (auto &e : h->ev) if (e) (void) hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
+{
+    if (!cfg || !out) return fail(IRB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->n_instances < 1 || cfg->channels < 1 || cfg->block < 1 || cfg->max_ir_len < 1 || cfg->max_blocks_per_call < 1)
+        return fail(IRB_ERR_ARG, "n_instances, channels, block, max_ir_len and max_blocks_per_call must be >= 1");
+    if (cfg->block > 2048) return fail(IRB_ERR_ARG, "block %d > 2048 not supported", cfg->block);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(IRB_ERR_HIP, "device %d not present (%d HIP devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    irb_fdl *h = new (std::nothrow) irb_fdl;
+    if (!h) return fail(IRB_ERR_ARG, "out of host memory");
+    h->device = cfg->device;
+    h->I = cfg->n_instances; h->C = cfg->channels; h->S = h->I * h->C;
+    h->B = cfg->block; h->N = fft_len_for_block(h->B); h->M = h->N / 2;
+    h->P = (cfg->max_ir_len + h->B - 1) / h->B;
+    h->R = h->P;
+    h->Tmax = cfg->max_blocks_per_call;
+    h->flags = cfg->flags;
+    h->splits = choose_splits(h);
+
+    int rc = IRB_OK;
+    auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };
+    do {
+        if (cfg->stream) { h->stream = static_cast<hipStream_t>(cfg->stream); }
+        else {
+            hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+            h->own_stream = true;
+        }
+        for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventCreate failed"); break; }
+        if (rc != IRB_OK) break;
+        const size_t SM = (size_t) h->S * h->M;
+        if (!guard(dev_alloc(h, &h->d_H, SM * h->P))) break;
+        if (!guard(dev_alloc(h, &h->d_X, SM * h->R))) break;
+        if (!guard(dev_alloc(h, &h->d_tw, (size_t) h->N))) break;
+        if (!guard(dev_alloc(h, &h->d_part, SM * std::max(h->splits, 1)))) break;
+        if (!guard(dev_alloc(h, &h->d_ovl, (size_t) h->S * h->B))) break;
+        if (!guard(dev_alloc(h, &h->d_in, (size_t) h->S * h->Tmax * h->B))) break;
+        if (!guard(dev_alloc(h, &h->d_out, (size_t) h->S * h->Tmax * h->B))) break;
+        if (!guard(dev_alloc(h, &h->d_irtime, (size_t) h->C * h->P * h->B))) break;
+        if (!guard(dev_alloc(h, &h->d_set_of_stream, (size_t) h->S))) break;
+        if (!guard(dev_alloc(h, &h->d_np_of_set, (size_t) h->S))) break;
+        hipError_t e;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) h->S * h->Tmax * h->B)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_set_of_stream), sizeof(int) * h->S)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess) {
+            rc = fail(IRB_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
+            break;
+        }
+        // twiddles: W_N^j in double, rounded to float
+        std::vector<float2> tw(h->N);
+        for (int j = 0; j < h->N; j++) {
+            const double ph = -2.0 * 3.14159265358979323846 * (double) j / (double) h->N;
+            tw[j] = make_float2((float) std::cos(ph), (float) std::sin(ph));
+        }
+        if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * h->N, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * SM * h->P, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) h->S * h->B, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_in, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_out, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess) {
+            rc = fail(IRB_ERR_HIP, "device init: %s", hipGetErrorString(e));
+            break;
+        }
+        for (int s = 0; s < h->S; s++) { h->h_set_of_stream[s] = s; h->h_np_of_set[s] = 0; }   // no IR yet: output is silence
+        if (!guard(upload_maps(h))) break;
+        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = fail(IRB_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc != IRB_OK) { char keep[sizeof g_err]; std::memcpy(keep, g_err, sizeof keep); irb_fdl_destroy(h); std::memcpy(g_err, keep, sizeof keep); return rc; }
+    *out = h;
+    return IRB_OK;
+}
+
+int irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info)
+{
+    if (!h || !info) return fail(IRB_ERR_ARG, "null argument");
+    info->fft_len = h->N; info->partitions = h->P; info->ring_slots = h->R; info->streams = h->S;
+    info->splits = h->splits; info->device_bytes = h->bytes;
+    info->algorithmic_bytes_per_block_step = 8.0 * h->P * h->N + 16.0 * h->B;
+    return IRB_OK;
+}
+
+int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_channels, int len)
+{
+    if (!h || !ir) return fail(IRB_ERR_ARG, "null argument");
+    if (instance < 0 || instance >= h->I) return fail(IRB_ERR_ARG, "instance %d out of range [0,%d)", instance, h->I);
+    if (len < 0 || len > h->P * h->B) return fail(IRB_ERR_ARG, "IR length %d exceeds max_ir_len capacity %d", len, h->P * h->B);
+    // fp/convolution.cpp:28-42: only mono/stereo IR x mono/stereo audio are known layouts
+    if (!((ir_channels == 1 || ir_channels == 2) && (h->C == 1 || h->C == 2)))
+        return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
+    for (int c = 0; c < ir_channels; c++) if (!ir[c] && len > 0) return fail(IRB_ERR_ARG, "ir[%d] is null", c);
+    HIP_TRY(hipSetDevice(h->device));
+    const int np = (len + h->B - 1) / h->B;
+    const int nrows = (ir_channels == 2 && h->C == 2) ? 2 : 1;        // fp/convolution.cpp:94-101
+    const size_t row = (size_t) np * h->B;
+    for (int r = 0; r < nrows; r++) {
+        float *dst = h->h_ir + r * row;
+        std::memcpy(dst, ir[r], sizeof(float) * (size_t) len);
+        std::fill(dst + len, dst + row, 0.0f);
+    }
+    if (ir_channels == 2 && h->C == 1) {                              // tools::sumToMono, fp/tools.cpp:25-28
+        float *p0 = h->h_ir;
+        for (int i = 0; i < len; i++) { p0[i] += ir[1][i]; p0[i] /= 2.0f; }
+    }
+    const int first_set = instance * h->C;
+    if (np > 0) {
+        HIP_TRY(hipMemcpyAsync(h->d_irtime, h->h_ir, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
+        int rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
+        if (rc != IRB_OK) return rc;
+    }
+    for (int c = 0; c < h->C; c++) {
+        h->h_set_of_stream[first_set + c] = first_set + (nrows == 2 ? c : 0);   // fp/convolution.cpp:176-181
+        h->h_np_of_set[first_set + c] = np;
+    }
+    int rc = upload_maps(h);
+    if (rc != IRB_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
+int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const float *samples)
+{
+    if (!h || !samples) return fail(IRB_ERR_ARG, "null argument");
+    if (instance < 0 || instance >= h->I) return fail(IRB_ERR_ARG, "instance %d out of range", instance);
+    if (partition < 0 || partition >= h->P) return fail(IRB_ERR_ARG, "partition %d out of range [0,%d)", partition, h->P);
+    HIP_TRY(hipSetDevice(h->device));
+    const int first_set = instance * h->C;
+    // the staging slot of this partition: a call may be enqueued P times before anything is synchronised
+    float *hs = h->h_ir + (size_t) partition * h->B;
+    float *ds = h->d_irtime + (size_t) partition * h->B;
+    std::memcpy(hs, samples, sizeof(float) * h->B);
+    HIP_TRY(hipMemcpyAsync(ds, hs, sizeof(float) * h->B, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_ir_fft(h, ds, 1, 1, first_set, partition);
+    if (rc != IRB_OK) return rc;
+    bool changed = false;
+    for (int c = 0; c < h->C; c++) {
+        if (h->h_set_of_stream[first_set + c] != first_set || h->h_np_of_set[first_set + c] != h->P) changed = true;
+        h->h_set_of_stream[first_set + c] = first_set;               // Source/PluginProcessor.cpp:485
+        h->h_np_of_set[first_set + c] = h->P;
+    }
+    if (changed) return upload_maps(h);
+    return IRB_OK;
+}
+
+int irb_fdl_reset(irb_fdl *h)
+{
+    if (!h) return fail(IRB_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) h->S * h->B, h->stream));
+    h->t = 0;
+    return IRB_OK;
+}
+
+int irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks)
+{
+    if (!h || !d_in || !d_out) return fail(IRB_ERR_ARG, "null argument");
+    if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
+    if (stride < (long) n_blocks * h->B && h->S > 1) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
+    HIP_TRY(hipSetDevice(h->device));
+    for (int j = 0; j < n_blocks; j++) {
+        irb::StepArgs a = step_args(h, d_in + (size_t) j * h->B, d_out + (size_t) j * h->B, stride);
+        int rc = launch_step(h, a);
+        if (rc != IRB_OK) return rc;
+        h->t++;
+    }
+    return IRB_OK;
+}
+
+int irb_fdl_synchronize(irb_fdl *h)
+{
+    if (!h) return fail(IRB_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
+int irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks)
+{
+    if (!h || !in || !out) return fail(IRB_ERR_ARG, "null argument");
+    if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
+    for (int s = 0; s < h->S; s++) if (!in[s] || !out[s]) return fail(IRB_ERR_ARG, "in/out[%d] is null", s);
+    HIP_TRY(hipSetDevice(h->device));
+    const long stride = (long) h->Tmax * h->B;
+    for (int done = 0; done < n_blocks; done += h->Tmax) {
+        const int nb = std::min(h->Tmax, n_blocks - done);
+        const size_t n = (size_t) nb * h->B;
+        for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
+        HIP_TRY(hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
+        int rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
+        if (rc != IRB_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, h->h_io + (size_t) s * stride, sizeof(float) * n);
+    }
+    return IRB_OK;
+}
+
+int irb_fdl_mark(irb_fdl *h, int slot)
+{
+    if (!h || slot < 0 || slot > 1) return fail(IRB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev[slot], h->stream));
+    return IRB_OK;
+}
+
+int irb_fdl_elapsed_ms(irb_fdl *h, float *ms)
+{
+    if (!h || !ms) return fail(IRB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev[0], h->ev[1]));
+    return IRB_OK;
+}
+
+int irb_fdl_device_io(irb_fdl *h, float **d_in, float **d_out, long *stride)
+{
+    if (!h || !d_in || !d_out || !stride) return fail(IRB_ERR_ARG, "null argument");
+    *d_in = h->d_in; *d_out = h->d_out; *stride = (long) h->Tmax * h->B;
+    return IRB_OK;
+}
+
+int irb_fdl_upload(irb_fdl *h, float *d_dst, const float *src, size_t n)
+{
+    if (!h || !d_dst || !src) return fail(IRB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, src, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
+int irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n)
+{
+    if (!h || !dst || !d_src) return fail(IRB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dst, d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp::convolution::convolvePeriodic (fp/convolution.cpp:14-242) as one call.
+// ---------------------------------------------------------------------------------------------
+int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, int La,
+                          const float *const *ir, int ir_ch, int Lh, int B, int keep_reference_tail,
+                          float *const *out)
+{
+    if (!audio || !ir || !out) return fail(IRB_ERR_ARG, "null argument");
+    if (La < 0 || Lh < 0 || B < 1 || audio_ch < 1) return fail(IRB_ERR_ARG, "negative length or block < 1");
+    const long Lout = (long) La + Lh - 1;
+    for (int c = 0; c < audio_ch; c++) {
+        if (!out[c]) return fail(IRB_ERR_ARG, "out[%d] is null", c);
+        if (Lout > 0) std::memset(out[c], 0, sizeof(float) * (size_t) Lout);       // :20-21
+    }
+    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2)))          // :28-42
+        return fail(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
+    if (Lh == 0 || Lout <= 0) return IRB_OK;
+    // :52 -- the reference takes ceil of a float ratio; samples beyond P*B are never read (:106-118)
+    const int P = (int) std::ceil((float) Lh / (float) B);
+    const int Lh_eff = (int) std::min<long>(Lh, (long) P * B);
+    const int T_last = La / B;                        // last block that holds audio (possibly empty), :128
+    long steps = (long) T_last + P;                   // :233
+    const long written = steps * B;
+    if (!keep_reference_tail && Lout > written) steps += 1;   // flush the overlap the reference drops (:236-238)
+
+    irb_fdl_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = Lh_eff;
+    cfg.max_blocks_per_call = (int) std::min<long>(steps, 4096);
+    irb_fdl *h = nullptr;
+    int rc = irb_fdl_create(&cfg, &h);
+    if (rc != IRB_OK) return rc;
+    rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
+    if (rc == IRB_OK) {
+        const long stride = (long) h->Tmax * h->B;
+        for (long done = 0; done < steps && rc == IRB_OK; done += h->Tmax) {
+            const int nb = (int) std::min<long>(h->Tmax, steps - done);
+            const long s0 = done * B, n = (long) nb * B;
+            for (int c = 0; c < audio_ch; c++) {
+                float *dst = h->h_io + (size_t) c * stride;
+                const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));
+                if (have > 0) std::memcpy(dst, audio[c] + s0, sizeof(float) * (size_t) have);
+                std::fill(dst + have, dst + n, 0.0f);
+            }
+            hipError_t e = hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+            rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
+            if (rc != IRB_OK) break;
+            e = hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
+            const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;
+            const long take = std::max<long>(0, std::min<long>(n, lim - s0));          // :225-227
+            for (int c = 0; c < audio_ch; c++)
+                if (take > 0) std::memcpy(out[c] + s0, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) take);
+        }
+    }
+    irb_fdl_destroy(h);
+    return rc;
+}
+
+}  // extern "C"

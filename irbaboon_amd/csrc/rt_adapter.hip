@@ -1,0 +1,176 @@
+// rt_adapter.hip -- processBlock-shaped host adapter (irb_rt_*) on top of the batched FDL engine.
+//
+// Mirrors the convolution part of IRBaboonAudioProcessor (reference Source/PluginProcessor.cpp):
+// ctor :57-82, prepareToPlay :164-234, processBlock IRCAP_IDLE branch :408-562.  The host keeps
+// exactly the reference's re-blocking state (input block buffer, output ring of host-block sized
+// buffers with the read index started at 1, sample counters); the per-block convolution step
+// (:452-518) runs on the GPU through irb_fdl_*.  Host-only C++; compiled into libirbfdl.so.
+//
+// Deliberate differences from the reference (SURVEY.md section 3.2 "quirks"):
+//  * The FDL ring always holds P distinct past blocks.  The reference sizes it
+//    max(P, ceil(hostBlock/256)) (:229-230) and writes all new spectra before processing any
+//    (:421-445), so with hostBlock > 256 its last partitions see a FUTURE block.
+//  * prepare_to_play always starts from a cleared FDL/overlap (the reference clears only when the
+//    ring grows, :213-215) and resets outputSampleIndex when it would index past the new host block.
+//  * irb_rt_set_ir checks the IR length instead of reading out of bounds (:457).
+#include "../../include/irb_fdl.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+struct irb_rt {
+    int device = 0, C = 0, B = 0, irRingLen = 0, P = 0, H = 0, latency = 0;
+    irb_fdl *eng = nullptr;
+    std::vector<float> ir;                    // IRtoConvolve (:411-414)
+    std::vector<float> inBlock;               // [C][B] block being filled (:421-426)
+    std::vector<float> ready;                 // [nb][C][B] complete blocks of this call
+    std::vector<float> conv;                  // [C][B] one processed block
+    std::vector<float> outRing;               // [outSize][C][H] (:210)
+    int outSize = 0, outRd = 0, outWr = 0;
+    int inputBufferSampleIndex = 0, outputBufferSampleIndex = 0, outputSampleIndex = 0;
+    int irWriteIndex = 0;                     // irFftBufferArray write index (:457-461)
+};
+
+namespace {
+
+int next_pow2(int x) { int p = 1; while (p < x) p *= 2; return p; }
+
+}  // namespace
+
+extern "C" int irb_set_error_(int code, const char *msg);   // fdl_engine.hip: sets irb_last_error(), returns code
+
+extern "C" {
+
+int irb_rt_create(int device, int channels, int block, int ir_ring_len, irb_rt **out)
+{
+    if (!out) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (channels < 1 || block < 1 || ir_ring_len < 1) return irb_set_error_(IRB_ERR_ARG, "channels, block, ir_ring_len must be >= 1");
+    irb_rt *p = new (std::nothrow) irb_rt;
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "out of host memory");
+    p->device = device; p->C = channels; p->B = block; p->irRingLen = ir_ring_len;
+    p->latency = block;                                                         // :59
+    p->P = (int) std::ceil((float) ir_ring_len / (float) block);                // :225
+    // default IR = tools::generatePulse(makeupIRLengthSamples, 100) (:46, fp/tools.cpp:235-241)
+    p->ir.assign((size_t) std::max(ir_ring_len, p->P * block), 0.0f);
+    p->ir[ir_ring_len > 100 ? 100 : 0] = 1.0f;
+    p->inBlock.assign((size_t) channels * block, 0.0f);
+    p->conv.assign((size_t) channels * block, 0.0f);
+    *out = p;
+    return IRB_OK;
+}
+
+void irb_rt_destroy(irb_rt *p)
+{
+    if (!p) return;
+    irb_fdl_destroy(p->eng);
+    delete p;
+}
+
+int irb_rt_release_resources(irb_rt *p)                                         // :240-248
+{
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "null handle");
+    irb_fdl_destroy(p->eng);
+    p->eng = nullptr;
+    p->outRing.clear(); p->outSize = 0;
+    return IRB_OK;
+}
+
+int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    // :164-234
+{
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "null handle");
+    if (samples_per_block < 1) return irb_set_error_(IRB_ERR_ARG, "samples_per_block must be >= 1");
+    p->H = samples_per_block;
+    p->latency = std::max(p->H, p->B);                                          // :169-174
+    p->outSize = next_pow2((int) std::ceil((float) p->B / (float) p->H) + 1);   // :205
+    p->outRing.assign((size_t) p->outSize * p->C * p->H, 0.0f);                 // :210
+    p->outRd = 1; p->outWr = 0;                                                 // :218
+    p->inputBufferSampleIndex = 0;                                              // :220
+    p->outputBufferSampleIndex = 0;                                             // :221
+    if (p->outputSampleIndex >= p->H) p->outputSampleIndex = 0;                 // reference: left as is (UB if too large)
+    std::fill(p->inBlock.begin(), p->inBlock.end(), 0.0f);
+    p->irWriteIndex = 0;                                                        // :226 clearAndResize
+    irb_fdl_destroy(p->eng);
+    p->eng = nullptr;
+    irb_fdl_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.device = p->device; cfg.n_instances = 1; cfg.channels = p->C; cfg.block = p->B;
+    cfg.max_ir_len = p->P * p->B; cfg.max_blocks_per_call = 1;
+    return irb_fdl_create(&cfg, &p->eng);
+}
+
+int irb_rt_set_ir(irb_rt *p, const float *ir, int len)
+{
+    if (!p || !ir) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (len < p->P * p->B) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "IR has %d samples, the rolling refresh reads %d (partitions*block)", len, p->P * p->B);
+        return irb_set_error_(IRB_ERR_ARG, msg);
+    }
+    p->ir.assign(ir, ir + len);
+    return IRB_OK;
+}
+
+int irb_rt_latency(const irb_rt *p) { return p ? p->latency : 0; }
+int irb_rt_partitions(const irb_rt *p) { return p ? p->P : 0; }
+
+int irb_rt_process_block(irb_rt *p, float *const *buffer, int n)                // :408-562
+{
+    if (!p || !buffer) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (!p->eng) return irb_set_error_(IRB_ERR_STATE, "process_block before prepare_to_play");
+    if (n == 0) return IRB_OK;                                                  // :281-283
+    if (n < 0) return irb_set_error_(IRB_ERR_ARG, "negative block length");
+    const int C = p->C, B = p->B, H = p->H;
+    for (int c = 0; c < C; c++) if (!buffer[c]) return irb_set_error_(IRB_ERR_ARG, "null channel pointer");
+
+    // :421-445 collect host samples into blocks of B
+    p->ready.clear();
+    for (int sample = 0; sample < n; sample++) {
+        for (int c = 0; c < C; c++) p->inBlock[(size_t) c * B + p->inputBufferSampleIndex] = buffer[c][sample];
+        if (++p->inputBufferSampleIndex >= B) {
+            p->ready.insert(p->ready.end(), p->inBlock.begin(), p->inBlock.end());
+            std::fill(p->inBlock.begin(), p->inBlock.end(), 0.0f);
+            p->inputBufferSampleIndex = 0;
+        }
+    }
+
+    // :452-518 one FDL step per complete block, then :525-543 into the output ring
+    const size_t nb = p->ready.size() / ((size_t) C * B);
+    std::vector<const float *> inp(C);
+    std::vector<float *> outp(C);
+    for (size_t j = 0; j < nb; j++) {
+        int rc = irb_fdl_set_ir_partition(p->eng, 0, p->irWriteIndex, p->ir.data() + (size_t) p->irWriteIndex * B);   // :455-461
+        if (rc != IRB_OK) return rc;
+        if (++p->irWriteIndex >= p->P) p->irWriteIndex = 0;
+        for (int c = 0; c < C; c++) { inp[c] = p->ready.data() + (j * C + c) * B; outp[c] = p->conv.data() + (size_t) c * B; }
+        rc = irb_fdl_process(p->eng, inp.data(), outp.data(), 1);
+        if (rc != IRB_OK) return rc;
+        for (int sample = 0; sample < B; sample++) {
+            float *w = p->outRing.data() + (size_t) p->outWr * C * H;
+            if (p->outputBufferSampleIndex == 0) std::fill(w, w + (size_t) C * H, 0.0f);
+            for (int c = 0; c < C; c++) w[(size_t) c * H + p->outputBufferSampleIndex] = p->conv[(size_t) c * B + sample];
+            if (++p->outputBufferSampleIndex >= H) {
+                if (++p->outWr >= p->outSize) p->outWr = 0;
+                p->outputBufferSampleIndex = 0;
+            }
+        }
+    }
+
+    // :550-560 output ring -> host buffer
+    for (int sample = 0; sample < n; sample++) {
+        const float *r = p->outRing.data() + (size_t) p->outRd * C * H;
+        for (int c = 0; c < C; c++) buffer[c][sample] = r[(size_t) c * H + p->outputSampleIndex];
+        if (++p->outputSampleIndex >= H) {
+            if (++p->outRd >= p->outSize) p->outRd = 0;
+            p->outputSampleIndex = 0;
+        }
+    }
+    return IRB_OK;
+}
+
+}  // extern "C"

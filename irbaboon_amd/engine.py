@@ -1,0 +1,91 @@
+"""FdlEngine: Python handle on the batched, device-resident FDL convolver (irb_fdl_*)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FdlConfig, FdlInfo, check, fp, planar_ptrs
+
+
+class FdlEngine:
+    """n_instances independent IR x stream instances of `channels` channels each, all with
+    block size `block` and IRs up to `max_ir_len` samples, resident on one MI355X.
+
+    Mirrors the state the reference keeps per plug-in instance (Source/PluginProcessor.h:194-217)
+    -- FDL ring, IR partition spectra, overlap -- batched over instances."""
+
+    def __init__(self, n_instances, channels, block, max_ir_len, max_blocks_per_call=1,
+                 device=0, stream=None, flags=0):
+        self._h = C.c_void_p()
+        cfg = FdlConfig(device, n_instances, channels, block, max_ir_len, max_blocks_per_call,
+                        C.c_void_p(stream) if stream else None, flags)
+        check(_lib.lib().irb_fdl_create(C.byref(cfg), C.byref(self._h)))
+        self.n_instances, self.channels, self.block = n_instances, channels, block
+        self.streams = n_instances * channels
+        self.max_blocks_per_call = max_blocks_per_call
+        info = FdlInfo()
+        check(_lib.lib().irb_fdl_get_info(self._h, C.byref(info)))
+        self.info = info
+
+    def close(self):
+        if self._h:
+            _lib.lib().irb_fdl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_ir(self, instance, ir):
+        """ir: float32 [ir_channels][len] (or 1-D for mono)."""
+        ir = np.ascontiguousarray(np.atleast_2d(ir), np.float32)
+        check(_lib.lib().irb_fdl_set_ir(self._h, instance, planar_ptrs(ir), ir.shape[0], ir.shape[1]))
+
+    def set_ir_partition(self, instance, partition, samples):
+        s = np.ascontiguousarray(samples, np.float32)
+        assert s.size == self.block
+        check(_lib.lib().irb_fdl_set_ir_partition(self._h, instance, partition, s.ctypes.data_as(fp)))
+
+    def reset(self):
+        check(_lib.lib().irb_fdl_reset(self._h))
+
+    def process(self, x):
+        """x: float32 [streams][n_blocks*block] (stream = instance*channels + channel); returns same shape."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.streams and x.shape[1] % self.block == 0
+        y = np.empty_like(x)
+        check(_lib.lib().irb_fdl_process(self._h, planar_ptrs(x), planar_ptrs(y), x.shape[1] // self.block))
+        return y
+
+    # ---- device-resident path (bench, smoke) ----
+    def device_io(self):
+        d_in, d_out, stride = C.c_void_p(), C.c_void_p(), C.c_long()
+        check(_lib.lib().irb_fdl_device_io(self._h, C.byref(d_in), C.byref(d_out), C.byref(stride)))
+        return d_in.value, d_out.value, stride.value
+
+    def upload(self, d_dst, src):
+        src = np.ascontiguousarray(src, np.float32)
+        check(_lib.lib().irb_fdl_upload(self._h, d_dst, src.ctypes.data_as(fp), src.size))
+
+    def download(self, d_src, n):
+        out = np.empty(n, np.float32)
+        check(_lib.lib().irb_fdl_download(self._h, out.ctypes.data_as(fp), d_src, n))
+        return out
+
+    def process_device(self, d_in, d_out, stride, n_blocks):
+        check(_lib.lib().irb_fdl_process_device(self._h, d_in, d_out, stride, n_blocks))
+
+    def synchronize(self):
+        check(_lib.lib().irb_fdl_synchronize(self._h))
+
+    def mark(self, slot):
+        check(_lib.lib().irb_fdl_mark(self._h, slot))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        check(_lib.lib().irb_fdl_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value

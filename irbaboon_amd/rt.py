@@ -1,0 +1,45 @@
+"""RtConvolver: the convolution part of IRBaboonAudioProcessor (prepareToPlay / processBlock /
+releaseResources, Source/PluginProcessor.cpp:164-248, 408-562) on the GPU through irb_rt_*."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, fp, planar_ptrs
+
+
+class RtConvolver:
+    def __init__(self, channels=2, block=256, ir_ring_len=2048, device=0):
+        self._h = C.c_void_p()
+        check(_lib.lib().irb_rt_create(device, channels, block, ir_ring_len, C.byref(self._h)))
+        self.channels = channels
+
+    def close(self):
+        if self._h:
+            _lib.lib().irb_rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def prepareToPlay(self, samplesPerBlock):
+        check(_lib.lib().irb_rt_prepare_to_play(self._h, samplesPerBlock))
+
+    def releaseResources(self):
+        check(_lib.lib().irb_rt_release_resources(self._h))
+
+    def setIR(self, ir):
+        ir = np.ascontiguousarray(ir, np.float32)
+        check(_lib.lib().irb_rt_set_ir(self._h, ir.ctypes.data_as(fp), ir.size))
+
+    def processBlock(self, buffer):
+        """buffer: float32 C-contiguous [channels][n], processed in place."""
+        assert buffer.dtype == np.float32 and buffer.flags.c_contiguous and buffer.shape[0] == self.channels
+        check(_lib.lib().irb_rt_process_block(self._h, planar_ptrs(buffer), buffer.shape[1]))
+
+    @property
+    def latency(self):
+        return _lib.lib().irb_rt_latency(self._h)
+
+    @property
+    def partitions(self):
+        return _lib.lib().irb_rt_partitions(self._h)

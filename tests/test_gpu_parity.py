@@ -1,0 +1,242 @@
+"""GPU parity tests (run on a real MI355X with -m gpu).  Everything goes through the C ABI
+(libirbfdl.so via ctypes) and is compared with the CPU oracle, the committed golden fixtures
+or float64 convolution.  Tolerance: the north star's 1e-5 relative RMS per channel (util.RMS_TOL);
+this is floating-point work, so bit-exactness is not expected (the MAC sums partitions in a
+different order than the reference's sequential loop, fp/convolution.cpp:171-202)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.signal
+
+import oracle
+from irbaboon_amd import FdlEngine, RtConvolver, _lib, convolvePeriodic
+from irbaboon_amd.synth import decaying_ir, delta_ir, white_noise
+from util import RMS_TOL, direct_f64, rel_rms, written_samples
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "convolve_cases.npz"))
+CASES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def _streams(I, C, n, seed):
+    return np.stack([white_noise(seed + 2 * i + c, n) for i in range(I) for c in range(C)])
+
+
+# (instances, channels, ir_channels, block, Lh, n_blocks)
+ENGINE_CASES = [
+    (1, 1, 1, 256, 4096, 40),
+    (3, 2, 2, 128, 700, 30),
+    (2, 2, 1, 128, 1000, 20),
+    (2, 1, 2, 64, 500, 25),
+    (2, 1, 1, 512, 3000, 12),
+    (1, 1, 1, 16, 100, 40),
+    (1, 1, 1, 100, 250, 20),
+    (1, 2, 2, 1024, 5000, 8),
+    (1, 1, 1, 2048, 5000, 5),
+    (5, 1, 1, 256, 96000, 6),
+]
+
+
+@pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_SPLIT, 0], ids=["fused", "split", "auto"])
+@pytest.mark.parametrize("case", ENGINE_CASES, ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
+def test_engine_streaming_matches_oracle(case, flags):
+    I, C, Cir, B, Lh, T = case
+    x = _streams(I, C, T * B, 100)
+    irs = [np.stack([decaying_ir(9000 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=7, flags=flags) as eng:
+        for i in range(I):
+            eng.set_ir(i, irs[i])
+        y = eng.process(x)
+        assert y.shape == x.shape
+        for i in range(I):
+            ref, rc = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+            assert rc == 0
+            for c in range(C):
+                assert rel_rms(y[i * C + c], ref[c, :T * B]) < RMS_TOL
+        # reset -> same input gives the same output again (FDL and overlap really cleared)
+        eng.reset()
+        y2 = eng.process(x)
+        assert np.array_equal(y, y2)
+
+
+def test_engine_without_ir_is_silent_and_ir_can_change():
+    B, Lh = 256, 2000
+    x = _streams(2, 1, 10 * B, 7)
+    with FdlEngine(2, 1, B, Lh) as eng:
+        assert not eng.process(x).any()
+        eng.set_ir(1, decaying_ir(1, Lh))
+        y = eng.process(x)
+        assert not y[0].any() and y[1].any()
+        eng.reset()
+        h2 = decaying_ir(2, 700)                       # shorter IR: fewer partitions in use
+        eng.set_ir(0, h2)
+        y = eng.process(x)
+        assert rel_rms(y[0], direct_f64(x[:1], h2[None])[0, :10 * B]) < RMS_TOL
+
+
+def test_engine_argument_errors():
+    with FdlEngine(1, 2, 128, 1000) as eng:
+        with pytest.raises(_lib.IrbError) as e:
+            eng.set_ir(0, np.zeros((3, 100), np.float32))
+        assert e.value.code == _lib.IRB_ERR_LAYOUT
+        with pytest.raises(_lib.IrbError) as e:
+            eng.set_ir(0, np.zeros((1, 5000), np.float32))
+        assert e.value.code == _lib.IRB_ERR_ARG
+        with pytest.raises(_lib.IrbError):
+            eng.set_ir(4, np.zeros((1, 10), np.float32))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_convolve_periodic_matches_golden_and_oracle(name):
+    audio, ir, B = GOLD[name + "/audio"], GOLD[name + "/ir"], int(GOLD[name + "/block"])
+    exp = GOLD[name + "/expected_f64"]
+    y = convolvePeriodic(audio, ir, B)
+    ref, _ = oracle.convolve_periodic(audio, ir, B)
+    nw = written_samples(audio.shape[1], ir.shape[1], B)
+    assert y.shape == exp.shape
+    for c in range(y.shape[0]):
+        assert rel_rms(y[c, :nw], exp[c, :nw]) < RMS_TOL
+        assert rel_rms(y[c, :nw], ref[c, :nw]) < RMS_TOL
+    assert np.all(y[:, nw:] == 0.0)                     # same dropped tail as the reference
+    full = convolvePeriodic(audio, ir, B, keep_reference_tail=False)
+    for c in range(y.shape[0]):
+        assert rel_rms(full[c], exp[c]) < RMS_TOL       # complete linear convolution on request
+
+
+def test_convolve_periodic_edge_cases():
+    h = decaying_ir(1, 40)[None]
+    assert not convolvePeriodic(np.zeros((1, 0), np.float32), h, 16).any()             # empty audio
+    y = convolvePeriodic(white_noise(1, 64)[None], np.zeros((1, 0), np.float32), 16)    # empty IR
+    assert y.shape == (1, 63) and not y.any()
+    y = convolvePeriodic(np.ones((3, 64), np.float32), h, 16)                           # unknown layout
+    assert y.shape == (3, 103) and not y.any()
+    x = white_noise(2, 1)[None]                                                          # single sample
+    y = convolvePeriodic(x, h, 16, keep_reference_tail=False)
+    assert rel_rms(y, direct_f64(x, h)) < RMS_TOL
+
+
+def test_delta_ir_is_pure_delay():
+    x = np.stack([white_noise(11, 8192), white_noise(12, 8192)])
+    y = convolvePeriodic(x, delta_ir()[None], 256)
+    assert np.abs(y[:, 100:100 + 8192] - x).max() < 3e-6 and np.abs(y[:, :100]).max() < 3e-6
+
+
+@pytest.mark.parametrize("host_block", [64, 100, 128, 256])
+def test_rt_adapter_matches_oracle(host_block):
+    """irb_rt_* against the restated processBlock, default delta IR then a general IR loaded by
+    the rolling refresh (Source/PluginProcessor.cpp:455-461)."""
+    ir = decaying_ir(5, 8 * 256)
+    for use_ir in (False, True):
+        ref = oracle.RtProcessor(2, 256, 2048)
+        gpu = RtConvolver(2, 256, 2048)
+        ref.prepare_to_play(host_block)
+        gpu.prepareToPlay(host_block)
+        assert gpu.latency == ref.latency and gpu.partitions == ref.partitions
+        if use_ir:
+            ref.set_ir(ir)
+            gpu.setIR(ir)
+        n = host_block * (256 * 30 // host_block)
+        x = np.stack([white_noise(41, n), white_noise(42, n)])
+        yr, yg = np.empty_like(x), np.empty_like(x)
+        for i in range(0, n, host_block):
+            a = np.ascontiguousarray(x[:, i:i + host_block])
+            b = a.copy()
+            ref.process_block(a)
+            gpu.processBlock(b)
+            yr[:, i:i + host_block], yg[:, i:i + host_block] = a, b
+        for c in range(2):
+            assert rel_rms(yg[c], yr[c]) < RMS_TOL
+        gpu.close()
+
+
+def test_rt_adapter_host_block_larger_than_block_is_causal():
+    """hostBlock 512 > 256: the reference's FDL ring is one slot short and feeds a future block to
+    its last partition; the adapter keeps P past blocks, so it must equal the true
+    streaming convolution.  The oracle, restating the reference, must NOT."""
+    P, B, H = 8, 256, 512
+    ir = decaying_ir(6, P * B)
+    gpu, ref = RtConvolver(2, B, P * B), oracle.RtProcessor(2, B, P * B)
+    gpu.prepareToPlay(H)
+    ref.prepare_to_play(H)
+    gpu.setIR(ir)
+    ref.set_ir(ir)
+    n = H * 30
+    x = np.stack([white_noise(51, n), white_noise(52, n)])
+    yg, yr = np.empty_like(x), np.empty_like(x)
+    for i in range(0, n, H):
+        a = np.ascontiguousarray(x[:, i:i + H])
+        b = a.copy()
+        gpu.processBlock(a)
+        ref.process_block(b)
+        yg[:, i:i + H], yr[:, i:i + H] = a, b
+    true = direct_f64(x, ir[None])[:, :n]
+    s = (P + 2) * B
+    assert rel_rms(yg[:, H + s:], true[:, s:n - H]) < RMS_TOL
+    assert rel_rms(yr[:, H + s:], true[:, s:n - H]) > 1e-3
+
+
+# ---- BASELINE.json full-size configurations: oracle where it finishes in seconds, otherwise
+# ---- size-independent properties (float64 FFT convolution, linearity, delta = delay)
+
+def test_cfg2_full_size_single_stream():
+    B, Lh, La = 256, 96000, 96000 * 4
+    x, h = white_noise(2000, La)[None], decaying_ir(18000, Lh)[None]
+    y = convolvePeriodic(x, h, B)
+    ref, _ = oracle.convolve_periodic(x, h, B)
+    assert rel_rms(y, ref) < RMS_TOL
+    assert rel_rms(y, scipy.signal.fftconvolve(x[0].astype(np.float64), h[0].astype(np.float64))[None]) < RMS_TOL
+
+
+def test_cfg3_full_size_stereo_long_ir_properties():
+    B, Lh, La = 128, 480000, 128 * 600
+    x = np.stack([white_noise(3000, La), white_noise(3001, La)])
+    h = np.stack([decaying_ir(27000, Lh), decaying_ir(27001, Lh)])
+    y = convolvePeriodic(x, h, B, keep_reference_tail=False)
+    assert y.shape == (2, La + Lh - 1)
+    for c in range(2):
+        ref = scipy.signal.fftconvolve(x[c].astype(np.float64), h[c].astype(np.float64))
+        assert rel_rms(y[c], ref) < RMS_TOL
+    # linearity: conv(a*x1 + x2) = a*conv(x1) + conv(x2)
+    x2 = np.stack([white_noise(3002, La), white_noise(3003, La)])
+    y2 = convolvePeriodic(x2, h, B, keep_reference_tail=False)
+    y3 = convolvePeriodic((0.5 * x + x2).astype(np.float32), h, B, keep_reference_tail=False)
+    assert rel_rms(y3, 0.5 * y.astype(np.float64) + y2) < RMS_TOL
+
+
+def test_cfg4_batched_instances_full_ir():
+    I, B, Lh, T = 48, 512, 96000, 6
+    x = _streams(I, 1, T * B, 4000)
+    with FdlEngine(I, 1, B, Lh, max_blocks_per_call=T) as eng:
+        assert eng.info.partitions == 188 and eng.info.fft_len == 1024
+        irs = [decaying_ir(36000 + 2 * i, Lh) for i in range(I)]
+        for i in range(I):
+            eng.set_ir(i, irs[i])
+        y = eng.process(x)
+        for i in (0, 1, 17, I - 1):
+            ref = scipy.signal.fftconvolve(x[i].astype(np.float64), irs[i].astype(np.float64))[:T * B]
+            assert rel_rms(y[i], ref) < RMS_TOL
+        # every instance is independent: permuting nothing else, instance 5 alone gives the same samples
+        with FdlEngine(1, 1, B, Lh, max_blocks_per_call=T, flags=_lib.FORCE_FUSED) as one:
+            one.set_ir(0, irs[5])
+            assert rel_rms(one.process(x[5:6])[0], y[5]) < 1e-6
+
+
+def test_device_resident_path_and_event_timer():
+    I, B, Lh, T = 4, 256, 4096, 8
+    x = _streams(I, 1, T * B, 60)
+    with FdlEngine(I, 1, B, Lh, max_blocks_per_call=T) as eng:
+        for i in range(I):
+            eng.set_ir(i, decaying_ir(70 + i, Lh))
+        ref = eng.process(x)
+        eng.reset()
+        d_in, d_out, stride = eng.device_io()
+        assert stride == T * B
+        eng.upload(d_in, x)
+        eng.mark(0)
+        eng.process_device(d_in, d_out, stride, T)
+        eng.mark(1)
+        assert eng.elapsed_ms() > 0.0
+        y = eng.download(d_out, I * stride).reshape(I, stride)
+        assert np.array_equal(y, ref)

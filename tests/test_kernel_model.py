@@ -1,0 +1,25 @@
+"""The numpy model of the HIP kernels' index/twiddle arithmetic (tests/kernel_model.py)
+against numpy's FFT: catches Stockham / split-pass / packing mistakes without a GPU."""
+import numpy as np
+import pytest
+
+from kernel_model import cmul_packed, irfft_packed, rfft_packed, stockham, twiddle_table
+
+
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_model(N):
+    rng = np.random.default_rng(N)
+    tw, M = twiddle_table(N), N // 2
+    z = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+    tol = 4e-7 * N
+    assert np.abs(stockham(z, tw, N) - np.fft.fft(z.astype(np.complex128))).max() < tol
+    assert np.abs(stockham(z, tw, N, True) - np.fft.ifft(z.astype(np.complex128)) * M).max() < tol
+    x = rng.standard_normal(N).astype(np.float32)
+    X, R = rfft_packed(x, N, tw), np.fft.rfft(x.astype(np.float64))
+    assert np.abs(X[1:] - R[1:M]).max() < tol
+    assert abs(X[0].real - R[0].real) < tol and abs(X[0].imag - R[M].real) < tol
+    assert np.abs(irfft_packed(X, N, tw) - x).max() < 2e-6
+    h = rng.standard_normal(N).astype(np.float32)
+    y = irfft_packed(cmul_packed(X, rfft_packed(h, N, tw)), N, tw)
+    ref = np.fft.irfft(np.fft.rfft(x.astype(np.float64)) * np.fft.rfft(h.astype(np.float64)))
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-6
