@@ -38,7 +38,7 @@ def cpu_baseline(seconds):
     t0 = time.perf_counter()
     oracle.convolve_periodic(probe, h, B)
     rate = (probe.shape[1] + LH) / (time.perf_counter() - t0)       # samples/s incl. the P-block tail
-    La = int(max(4, min(60, seconds * rate / LH - 1))) * LH
+    La = int(max(4, min(400, seconds * rate / LH - 1))) * LH
     x = white_noise(2001, La)[None]
     t0 = time.perf_counter()
     oracle.convolve_periodic(x, h, B)

@@ -1,0 +1,47 @@
+// C++ host-mirror test: irb::fp_convolution::convolvePeriodic with a minimal planar buffer type that
+// has juce::AudioBuffer<float>'s member names (this repository's own test type, JUCE is not needed).
+// usage: test_host_mirror layout   -> error convention only (no GPU needed)
+//        test_host_mirror gpu      -> delta-at-100 IR must give a pure 100-sample delay
+#include "../../include/irb_fp_convolution.hpp"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+struct PlanarBuffer {
+    PlanarBuffer(int ch, int n) : nch(ch), ns(n), d((size_t) ch * (size_t) (n > 0 ? n : 0)) {}
+    void clear() { std::fill(d.begin(), d.end(), 0.0f); }
+    int getNumChannels() const { return nch; }
+    int getNumSamples() const { return ns; }
+    const float *getReadPointer(int c) const { return d.data() + (size_t) c * ns; }
+    float *getWritePointer(int c) { return d.data() + (size_t) c * ns; }
+    int nch, ns;
+    std::vector<float> d;
+};
+
+int main(int argc, char **argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    {   // unknown layout: cleared buffer of the right shape (fp/convolution.cpp:20-21,39-42)
+        PlanarBuffer a(3, 64), h(1, 16);
+        for (auto &v : a.d) v = 1.0f;
+        for (auto &v : h.d) v = 1.0f;
+        PlanarBuffer y = irb::fp_convolution::convolvePeriodic(a, h, 16);
+        if (y.getNumChannels() != 3 || y.getNumSamples() != 79) return 1;
+        for (float v : y.d) if (v != 0.0f) return 2;
+    }
+    if (!gpu) { std::puts("layout ok"); return 0; }
+    PlanarBuffer a(2, 4096), h(1, 2048);
+    a.clear(); h.clear();
+    uint64_t s = 12345;
+    for (auto &v : a.d) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (float) ((int64_t) (s >> 40) - (1 << 23)) / (float) (1 << 23); }
+    h.getWritePointer(0)[100] = 1.0f;               // tools::generatePulse(2048, 100), Source/PluginProcessor.cpp:46
+    PlanarBuffer y = irb::fp_convolution::convolvePeriodic(a, h);   // default processBlockSize = 256
+    if (y.getNumSamples() != 4096 + 2048 - 1) return 3;
+    double worst = 0;
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < 4096; i++) worst = std::fmax(worst, std::fabs(y.getReadPointer(c)[i + 100] - a.getReadPointer(c)[i]));
+    std::printf("delta delay max err %.3g\n", worst);
+    return worst < 3e-6 ? 0 : 4;
+}
