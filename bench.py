@@ -68,7 +68,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    dev = ranks.local_rank
+    dev = ranks.local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
 
     I, K, W, NB = args.instances, args.steps, args.warmup, 8

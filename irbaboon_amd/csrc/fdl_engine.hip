@@ -49,6 +49,9 @@ struct irb_fdl {
     bool own_stream = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
+    int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
+    int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
+    size_t part_rows = 0;                    // capacity of d_part in spectrum rows
     unsigned flags = 0;
     long long t = 0;                         // block steps done since reset
     size_t bytes = 0;
@@ -96,14 +99,29 @@ int choose_splits(const irb_fdl *h)
     return s < 2 ? 1 : s;
 }
 
+constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
+
+// partition splits for a call of T blocks: enough workgroups to fill the chip, but every stripe keeps
+// at least two full window steps of partitions
+int tiled_splits(const irb_fdl *h, int T)
+{
+    const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
+    const int ntiles = (T + kTT - 1) / kTT;
+    const int by_work = std::max(1, (h->Ppad / kTT) / (stripes * 2));
+    const long wgs = (long) h->S * ntiles;
+    const int by_chip = (int) std::max<long>(1, (1024 + wgs - 1) / wgs);
+    return std::max(1, std::min(by_work, by_chip));
+}
+
 irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long stride)
 {
     irb::StepArgs a;
-    a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl; a.tw = h->d_tw;
+    a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
+    a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
     a.set_of_stream = h->d_set_of_stream; a.np_of_set = h->d_np_of_set;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
-    a.B = h->B; a.P = h->P; a.R = h->R; a.head = (int) (h->t % h->R); a.splits = h->splits;
+    a.B = h->B; a.P = h->Ppad; a.R = h->R; a.head = (int) (h->t % h->R); a.splits = h->splits;
     return a;
 }
 
@@ -113,17 +131,35 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
         FOR_N(h->N, irb::k_step_fused<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
     } else {
         FOR_N(h->N, irb::k_push_fft<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
-        FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->splits, h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+        FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a));
         FOR_N(h->N, irb::k_reduce_ifft_ola<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
     }
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
 
+// T > 1 blocks of every stream in three launches (see fdl_kernels.hpp, time-tiled path)
+int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
+{
+    const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
+    a.T = T;
+    a.splits = tiled_splits(h, T);
+    a.nq = a.splits * stripes;
+    a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
+    if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
+    const int ntiles = (T + kTT - 1) / kTT;
+    FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3(h->S * T), dim3(irb::kThreads), 0, h->stream>>>(a));
+    FOR_N(h->N, irb::k_cmac_tiled<NN, kTT><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a));
+    FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3(h->S * T), dim3(irb::kThreads), 0, h->stream>>>(a));
+    HIP_TRY(hipGetLastError());
+    h->ovl_cur ^= 1;
+    return IRB_OK;
+}
+
 int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int first_set, int first_partition)
 {
     FOR_N(h->N, irb::k_ir_fft<NN><<<dim3(nparts, nrows), dim3(irb::kThreads), 0, h->stream>>>(
-                    d_ir, h->d_H, h->d_tw, h->B, h->P, first_set, first_partition));
+                    d_ir, h->d_H, h->d_tw, h->B, h->Ppad, first_set, first_partition));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
@@ -178,8 +214,9 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->I = cfg->n_instances; h->C = cfg->channels; h->S = h->I * h->C;
     h->B = cfg->block; h->N = fft_len_for_block(h->B); h->M = h->N / 2;
     h->P = (cfg->max_ir_len + h->B - 1) / h->B;
-    h->R = h->P;
+    h->Ppad = (h->P + kTT - 1) / kTT * kTT;
     h->Tmax = cfg->max_blocks_per_call;
+    h->R = h->Tmax > 1 ? h->Ppad + h->Tmax + kTT : h->P;     // tiled path: P past blocks + the call's blocks + tile overhang
     h->flags = cfg->flags;
     h->splits = choose_splits(h);
 
@@ -195,11 +232,17 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc != IRB_OK) break;
         const size_t SM = (size_t) h->S * h->M;
-        if (!guard(dev_alloc(h, &h->d_H, SM * h->P))) break;
+        if (!guard(dev_alloc(h, &h->d_H, SM * h->Ppad))) break;
         if (!guard(dev_alloc(h, &h->d_X, SM * h->R))) break;
         if (!guard(dev_alloc(h, &h->d_tw, (size_t) h->N))) break;
-        if (!guard(dev_alloc(h, &h->d_part, SM * std::max(h->splits, 1)))) break;
-        if (!guard(dev_alloc(h, &h->d_ovl, (size_t) h->S * h->B))) break;
+        {
+            const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
+            size_t rows = (size_t) h->S * std::max(h->splits, 1);
+            for (int T = 2; T <= h->Tmax; T++) rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
+            h->part_rows = rows;
+        }
+        if (!guard(dev_alloc(h, &h->d_part, h->part_rows * h->M))) break;
+        if (!guard(dev_alloc(h, &h->d_ovl, (size_t) 2 * h->S * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_in, (size_t) h->S * h->Tmax * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_out, (size_t) h->S * h->Tmax * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_irtime, (size_t) h->C * h->P * h->B))) break;
@@ -220,9 +263,9 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             tw[j] = make_float2((float) std::cos(ph), (float) std::sin(ph));
         }
         if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * h->N, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * SM * h->P, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * SM * h->Ppad, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
-            (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) h->S * h->B, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_in, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_out, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "device init: %s", hipGetErrorString(e));
@@ -274,6 +317,11 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
         int rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
         if (rc != IRB_OK) return rc;
     }
+    // the time-tiled kernel walks partitions in groups of kTT: rows up to the next multiple stay zero
+    const int np_pad = std::min((np + kTT - 1) / kTT * kTT, h->Ppad);
+    for (int r = 0; r < nrows && np_pad > np; r++)
+        HIP_TRY(hipMemsetAsync(h->d_H + ((size_t) (first_set + r) * h->Ppad + np) * h->M, 0,
+                               sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
     for (int c = 0; c < h->C; c++) {
         h->h_set_of_stream[first_set + c] = first_set + (nrows == 2 ? c : 0);   // fp/convolution.cpp:176-181
         h->h_np_of_set[first_set + c] = np;
@@ -313,8 +361,9 @@ int irb_fdl_reset(irb_fdl *h)
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) h->S * h->B, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream));
     h->t = 0;
+    h->ovl_cur = 0;
     return IRB_OK;
 }
 
@@ -324,11 +373,13 @@ int irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long str
     if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
     if (stride < (long) n_blocks * h->B && h->S > 1) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
     HIP_TRY(hipSetDevice(h->device));
-    for (int j = 0; j < n_blocks; j++) {
+    for (int j = 0; j < n_blocks;) {
+        const int T = std::min(n_blocks - j, h->Tmax);
         irb::StepArgs a = step_args(h, d_in + (size_t) j * h->B, d_out + (size_t) j * h->B, stride);
-        int rc = launch_step(h, a);
+        int rc = (T > 1) ? launch_tiled(h, a, T) : launch_step(h, a);
         if (rc != IRB_OK) return rc;
-        h->t++;
+        h->t += T;
+        j += T;
     }
     return IRB_OK;
 }

@@ -22,7 +22,7 @@ namespace irb {
 constexpr int kThreads = 256;
 
 struct StepArgs {
-    const float2 *H;            // [n_sets][P][M]
+    const float2 *H;            // [n_sets][P][M]  (P here = allocated rows per set, a multiple of 8)
     float2       *X;            // [S][R][M]
     float        *ovl;          // [S][B]
     const float2 *tw;           // [N]
@@ -33,6 +33,9 @@ struct StepArgs {
     float2       *part;         // [S][splits][M] partial sums (split path)
     long          in_stride, out_stride;
     int           B, P, R, head, splits;
+    // time-tiled path (several blocks per call)
+    float        *ovl_next;     // overlap written by the last block of the call (double buffered)
+    int           T, nq;        // blocks in this call; partial rows per output (splits * stripes)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 // ---------------------------------------------------------------------------------------------
 // Split path, for few streams with long IRs (one workgroup per stream cannot fill the chip):
 //   k_push_fft        grid = S            new block -> FFT -> ring slot `head`
-//   k_cmac_partial    grid = (splits, S)  partial sums over a contiguous partition range
+//   k_cmac_partial    grid = S*splits     partial sums over a contiguous partition range
 //   k_reduce_ifft_ola grid = S            sum of the partials -> IFFT -> overlap-add
 // ---------------------------------------------------------------------------------------------
 template <int N>
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_cmac_partial(StepArgs a)
     constexpr int M = N / 2;
     __shared__ float2 part[G::STRIPES * M];
     __shared__ float2 Y[M];
-    const int j = blockIdx.x, s = blockIdx.y;
+    const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
     const int set = a.set_of_stream[s];
     const int np = a.np_of_set[set];
     const int kb = (int) ((long) np * j / a.splits), ke = (int) ((long) np * (j + 1) / a.splits);
@@ -365,6 +368,170 @@ __global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
     float2 *z = fft_lds<M, true>(lb, la, a.tw);
     overlap_add(reinterpret_cast<const float *>(z), 1.0f / (float) N, a.B,
                 a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Time-tiled path: a call that carries T > 1 new blocks per stream (host blocks larger than B, or the
+// whole signal in the offline function).  All T input spectra are pushed first, then every output
+//   Y_{j}[b] = sum_k X_{t0+j-k}[b] * H_k[b],  j = 0..T-1
+// is independent, and TT consecutive outputs share their H loads: a lane keeps a sliding window of
+// 2*TT-1 X rows and TT accumulators in registers (per outer step: TT new X rows + TT H rows feed
+// TT*TT complex multiply-adds per bin).  HBM/L2 traffic per output drops by ~TT versus streaming.
+//   k_push_fft_batch   grid = S*T (block index fastest)
+//   k_cmac_tiled       grid = S*ceil(T/TT)*splits: stripes own contiguous partition sub-ranges and
+//                      write their partial spectra straight from registers: part[s][j][q][M]
+//   k_ifft_ola_batch   grid = S*T: sums the nq partials of block j and of block j-1 (for its tail)
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_push_fft_batch(StepArgs a)
+{
+    constexpr int M = N / 2;
+    __shared__ float2 la[M], lb[M];
+    const int j = blockIdx.x % a.T, s = blockIdx.x / a.T;
+    load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, la);
+    __syncthreads();
+    float2 *Z = fft_lds<M, false>(la, lb, a.tw);
+    float2 *Xn = (Z == la) ? lb : la;
+    split_forward<M>(Z, Xn, a.tw);
+    __syncthreads();
+    int slot = a.head + j;
+    if (slot >= a.R) slot -= a.R;
+    float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
+    for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Xn[b];
+}
+
+// XCD-aware workgroup id: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
+// its own 4 MiB L2); this bijection gives every XCD one contiguous range of ids instead, so workgroups
+// that share X/H rows (neighbouring time tiles) also share an L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+__device__ __forceinline__ int ring_slot(int head, int d, int R)
+{
+    int sl = head + d;
+    if (sl < 0) sl += R;
+    if (sl >= R) sl -= R;
+    return sl;
+}
+
+// one complex-pair multiply-accumulate; `first_is_packed` lanes treat the first complex of the float4
+// as packed bin 0 = two real bins: p = 0, q = h.y there (see k_cmac_tiled)
+__device__ __forceinline__ void cmac2(float4 &acc, const float4 x, const float4 h, float p, float q)
+{
+    acc.x = fmaf(x.x, h.x, acc.x);  acc.x = fmaf(-x.y, p, acc.x);
+    acc.y = fmaf(x.x, p, acc.y);    acc.y = fmaf(x.y, q, acc.y);
+    acc.z = fmaf(x.z, h.z, acc.z);  acc.z = fmaf(-x.w, h.w, acc.z);
+    acc.w = fmaf(x.z, h.w, acc.w);  acc.w = fmaf(x.w, h.z, acc.w);
+}
+
+template <int N, int TT>
+__global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2;
+    const int ntiles = (a.T + TT - 1) / TT;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
+    const int set = a.set_of_stream[s];
+    const int np = a.np_of_set[set];
+    const int col0 = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
+    const int q = split * G::STRIPES + stripe;
+    // whole groups of TT partitions per worker (worker = one stripe of one split).  The H rows between
+    // np and the next multiple of TT are kept at zero by the host, so there is no remainder loop.
+    const int nG = (np + TT - 1) / TT, nW = a.splits * G::STRIPES;
+    const int sb = (int) ((long) nG * q / nW) * TT, se = (int) ((long) nG * (q + 1) / nW) * TT;
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
+
+#pragma unroll 1
+    for (int c = 0; c < G::CPT; c++) {
+        const int col = col0 + c * G::LW;
+        const bool packed = (col == 0);
+        float4 acc[TT];
+#pragma unroll
+        for (int j = 0; j < TT; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        int k0 = sb;
+        if (k0 < se) {
+            // window xr[i] = X_{t0 + base + i}, base = j0 - k0 - (TT-1)
+            float4 xr[2 * TT - 1];
+#pragma unroll
+            for (int i = TT; i < 2 * TT - 1; i++)
+                xr[i] = X4[(size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col];
+            for (; k0 < se; k0 += TT) {
+                float4 h[TT];
+#pragma unroll
+                for (int u = 0; u < TT; u++) h[u] = H4[(size_t) (k0 + u) * G::L + col];
+#pragma unroll
+                for (int i = 0; i < TT; i++)
+                    xr[i] = X4[(size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col];
+#pragma unroll
+                for (int u = 0; u < TT; u++) {
+                    const float p = packed ? 0.0f : h[u].y;
+                    const float qq = packed ? h[u].y : h[u].x;
+#pragma unroll
+                    for (int j = 0; j < TT; j++) cmac2(acc[j], xr[j - u + TT - 1], h[u], p, qq);
+                }
+#pragma unroll
+                for (int i = 2 * TT - 2; i >= TT; i--) xr[i] = xr[i - TT];   // next step: base -= TT
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TT; j++) {
+            if (j0 + j < a.T) {
+                float4 *dst = reinterpret_cast<float4 *>(a.part + (((size_t) s * a.T + j0 + j) * a.nq + q) * M);
+                dst[col] = acc[j];
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_ifft_ola_batch(StepArgs a)
+{
+    constexpr int M = N / 2;
+    __shared__ float2 la[M], lb[M];
+    __shared__ float tail[M];             // B <= N/2 = M
+    const int j = blockIdx.x % a.T, s = blockIdx.x / a.T;
+    const float scale = 1.0f / (float) N;
+    // tail of the previous block of this call, or the saved overlap for the first block
+    if (j > 0) {
+        const float2 *src = a.part + ((size_t) s * a.T + (j - 1)) * a.nq * M;
+        for (int b = threadIdx.x; b < M; b += kThreads) {
+            float2 v = src[b];
+            for (int q = 1; q < a.nq; q++) v = cadd(v, src[(size_t) q * M + b]);
+            la[b] = v;
+        }
+        __syncthreads();
+        split_inverse<M>(la, lb, a.tw);
+        __syncthreads();
+        const float *y = reinterpret_cast<const float *>(fft_lds<M, true>(lb, la, a.tw));
+        for (int i = threadIdx.x; i < a.B; i += kThreads) tail[i] = y[a.B + i] * scale;
+    } else {
+        const float *ov = a.ovl + (size_t) s * a.B;
+        for (int i = threadIdx.x; i < a.B; i += kThreads) tail[i] = ov[i];
+    }
+    __syncthreads();
+    const float2 *src = a.part + ((size_t) s * a.T + j) * a.nq * M;
+    for (int b = threadIdx.x; b < M; b += kThreads) {
+        float2 v = src[b];
+        for (int q = 1; q < a.nq; q++) v = cadd(v, src[(size_t) q * M + b]);
+        la[b] = v;
+    }
+    __syncthreads();
+    split_inverse<M>(la, lb, a.tw);
+    __syncthreads();
+    const float *y = reinterpret_cast<const float *>(fft_lds<M, true>(lb, la, a.tw));
+    float *out = a.out + (size_t) s * a.out_stride + (size_t) j * a.B;
+    for (int i = threadIdx.x; i < a.B; i += kThreads) out[i] = y[i] * scale + tail[i];
+    if (j == a.T - 1) {
+        float *on = a.ovl_next + (size_t) s * a.B;
+        for (int i = threadIdx.x; i < a.B; i += kThreads) on[i] = y[a.B + i] * scale;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

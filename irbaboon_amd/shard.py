@@ -32,14 +32,18 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         self._dist = None
         self._device = "cpu"
+        self.backend = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
+            ndev = torch.cuda.device_count()
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # one rank per GPU over RCCL; ranks sharing a GPU (rehearsals on a 1-GPU box) use gloo
+                backend = "nccl" if ndev >= int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) and ndev > 0 else "gloo"
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self._device = f"cuda:{self.local_rank}"
+            self.backend = backend
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)

@@ -1,0 +1,52 @@
+"""Ad-hoc timing probes on the GPU box (not part of the bench contract).
+usage: python tools/perf_probe.py offline|batched|single [args]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from irbaboon_amd import FdlEngine, _lib
+from irbaboon_amd.synth import decaying_ir, white_noise
+
+
+def timed(eng, d_in, d_out, stride, T, reps):
+    eng.process_device(d_in, d_out, stride, T); eng.synchronize()
+    eng.mark(0)
+    for _ in range(reps):
+        eng.process_device(d_in, d_out, stride, T)
+    eng.mark(1)
+    return eng.elapsed_ms() / reps
+
+
+def offline(B=256, Lh=96000, T=3750, S=1):
+    """one call carrying T blocks per stream (time-tiled path)"""
+    eng = FdlEngine(S, 1, B, Lh, max_blocks_per_call=T)
+    for i in range(S):
+        eng.set_ir(i, decaying_ir(1 + i, Lh))
+    d_in, d_out, stride = eng.device_io()
+    eng.upload(d_in, np.stack([white_noise(5 + i, T * B) for i in range(S)]))
+    ms = timed(eng, d_in, d_out, stride, T, 5)
+    P, N = eng.info.partitions, eng.info.fft_len
+    flops = 8.0 * P * (N // 2) * T * S
+    print(f"tiled B={B} Lh={Lh} P={P} T={T} S={S}: {ms:.3f} ms/call  {S*T*B/ms/1e3:.1f} Msamples/s  "
+          f"{flops/ms/1e9:.2f} TFLOP/s (MAC only)  ring={eng.info.ring_slots}")
+
+
+def single(B=256, Lh=96000, n=2000, flags=0):
+    eng = FdlEngine(1, 1, B, Lh, max_blocks_per_call=1, flags=flags)
+    eng.set_ir(0, decaying_ir(1, Lh))
+    d_in, d_out, stride = eng.device_io()
+    eng.upload(d_in, white_noise(5, B))
+    eng.process_device(d_in, d_out, stride, 1); eng.synchronize()
+    t0 = time.perf_counter()
+    eng.mark(0)
+    for _ in range(n):
+        eng.process_device(d_in, d_out, stride, 1)
+    eng.mark(1)
+    ms = eng.elapsed_ms()
+    wall = time.perf_counter() - t0
+    print(f"single stream B={B} Lh={Lh} splits={eng.info.splits}: device {ms/n*1e3:.2f} us/block, host-inclusive {wall/n*1e6:.2f} us/block")
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    args = [int(a) for a in sys.argv[2:]]
+    {"offline": offline, "single": single}[mode](*args)
