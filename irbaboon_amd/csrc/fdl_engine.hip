@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -50,6 +51,7 @@ struct irb_fdl {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
+    bool nt = false;                         // non-temporal row loads in the fused kernel
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
     unsigned flags = 0;
@@ -128,7 +130,10 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
 int launch_step(irb_fdl *h, const irb::StepArgs &a)
 {
     if (h->splits <= 1) {
-        FOR_N(h->N, irb::k_step_fused<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+        // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
+        // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
+        if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 4, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else       { FOR_N(h->N, irb::k_step_fused<NN, 4, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else {
         FOR_N(h->N, irb::k_push_fft<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
         FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a));
@@ -219,6 +224,8 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->R = h->Tmax > 1 ? h->Ppad + h->Tmax + kTT : h->P;     // tiled path: P past blocks + the call's blocks + tile overhang
     h->flags = cfg->flags;
     h->splits = choose_splits(h);
+    h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
+    if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };

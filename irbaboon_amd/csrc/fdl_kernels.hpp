@@ -163,7 +163,19 @@ struct MacGeom {
     static constexpr int STRIPES = kThreads / LW;                 // partitions in flight per pass
 };
 
-template <int N, int U>
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// 16-byte global load; NT = non-temporal hint for rows that are streamed once per step
+template <bool NT>
+__device__ __forceinline__ float4 ld16(const float4 *p)
+{
+    if (NT) {
+        const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
+template <int N, int U, bool NT = false>
 __device__ __forceinline__ void mac_range(const float4 *__restrict__ H4, const float4 *__restrict__ X4,
                                           int kb, int ke, int head, int R,
                                           float4 (&acc)[MacGeom<N>::CPT], float2 &dc)
@@ -182,8 +194,8 @@ __device__ __forceinline__ void mac_range(const float4 *__restrict__ H4, const f
             if (slot < 0) slot += R;
 #pragma unroll
             for (int c = 0; c < G::CPT; c++) {
-                h[u][c] = H4[(size_t) kk * G::L + col + c * G::LW];
-                x[u][c] = X4[(size_t) slot * G::L + col + c * G::LW];
+                h[u][c] = ld16<NT>(H4 + (size_t) kk * G::L + col + c * G::LW);
+                x[u][c] = ld16<NT>(X4 + (size_t) slot * G::L + col + c * G::LW);
             }
         }
 #pragma unroll
@@ -204,8 +216,8 @@ __device__ __forceinline__ void mac_range(const float4 *__restrict__ H4, const f
         if (slot < 0) slot += R;
 #pragma unroll
         for (int c = 0; c < G::CPT; c++) {
-            const float4 h = H4[(size_t) k * G::L + col + c * G::LW];
-            const float4 x = X4[(size_t) slot * G::L + col + c * G::LW];
+            const float4 h = ld16<NT>(H4 + (size_t) k * G::L + col + c * G::LW);
+            const float4 x = ld16<NT>(X4 + (size_t) slot * G::L + col + c * G::LW);
             if (c == 0) { dc.x += x.x * h.x; dc.y += x.y * h.y; }
             acc[c].x += x.x * h.x - x.y * h.y;
             acc[c].y += x.x * h.y + x.y * h.x;
@@ -253,7 +265,7 @@ struct Lds {
 //   input block -> FFT -> ring slot `head`; MAC over all partitions; IFFT; overlap-add; output.
 // grid = S.  The dominant kernel when many streams are batched (HBM-bound, 8*P*N + 16*B bytes).
 // ---------------------------------------------------------------------------------------------
-template <int N>
+template <int N, int U = 4, bool NT = false>
 __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 {
     using G = MacGeom<N>;
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 #pragma unroll
     for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
-    mac_range<N, 4>(H4, X4, 1, np, a.head, a.R, acc, dc);
+    mac_range<N, U, NT>(H4, X4, 1, np, a.head, a.R, acc, dc);
 
     // new block: FFT, store into the ring, and its product with partition 0
     load_block<M>(a.in + (size_t) s * a.in_stride, a.B, lds.a);
