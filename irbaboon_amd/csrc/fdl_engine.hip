@@ -132,10 +132,10 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
     if (h->splits <= 1) {
         // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
         // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
-        if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 4, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        else       { FOR_N(h->N, irb::k_step_fused<NN, 4, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else {
-        FOR_N(h->N, irb::k_push_fft<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+        FOR_N(h->N, irb::k_push_fft<NN><<<dim3((h->S + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
         FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a));
         FOR_N(h->N, irb::k_reduce_ifft_ola<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
     }
@@ -153,9 +153,9 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
     const int ntiles = (T + kTT - 1) / kTT;
-    FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3(h->S * T), dim3(irb::kThreads), 0, h->stream>>>(a));
+    FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
     FOR_N(h->N, irb::k_cmac_tiled<NN, kTT><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a));
-    FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3(h->S * T), dim3(irb::kThreads), 0, h->stream>>>(a));
+    FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
     h->ovl_cur ^= 1;
     return IRB_OK;
@@ -163,8 +163,9 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
 
 int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int first_set, int first_partition)
 {
-    FOR_N(h->N, irb::k_ir_fft<NN><<<dim3(nparts, nrows), dim3(irb::kThreads), 0, h->stream>>>(
-                    d_ir, h->d_H, h->d_tw, h->B, h->Ppad, first_set, first_partition));
+    FOR_N(h->N, irb::k_ir_fft<NN><<<dim3((nparts * nrows + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF),
+                                     dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(
+                    d_ir, h->d_H, h->d_tw, h->B, h->Ppad, first_set, first_partition, nparts, nrows));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }

@@ -17,9 +17,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fft_wave.hpp"
+
 namespace irb {
 
 constexpr int kThreads = 256;
+
+// transforms per workgroup in the FFT-only kernels (one wave each); LDS = NF*M*8 + N*4 bytes
+template <int N> struct FftGeom { static constexpr int NF = N <= 2048 ? 4 : 2; };
 
 struct StepArgs {
     const float2 *H;            // [n_sets][P][M]  (P here = allocated rows per set, a multiple of 8)
@@ -38,111 +43,11 @@ struct StepArgs {
     int           T, nq;        // blocks in this call; partial rows per output (splits * stripes)
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { /* a * conj(b) */ return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-
-// ---------------------------------------------------------------------------------------------
-// M-point complex FFT in LDS: autosort Stockham, radix-4 stages then one radix-2 stage if log2 M
-// is odd.  One thread per butterfly, ping-pong between a and b; returns the buffer holding the
-// result.  Callers must __syncthreads() after filling `a`; the function ends with a barrier.
-// (Index arithmetic is modelled and checked on the CPU by tests/kernel_model.py.)
-// ---------------------------------------------------------------------------------------------
-template <int M, bool INV>
-__device__ __forceinline__ float2 *fft_lds(float2 *a, float2 *b, const float2 *__restrict__ tw)
+// Overlap-add (reference fp/convolution.cpp:209-213) by one wave: y = N real samples, unscaled, in LDS.
+__device__ __forceinline__ void wave_overlap_add(const float *y, float scale, int B, float *__restrict__ ovl,
+                                                 float *__restrict__ out, int lane)
 {
-    constexpr int N = 2 * M;
-    int Ns = 1;
-#pragma unroll 1
-    for (; Ns * 4 <= M; Ns *= 4) {
-        const int stride = M / 4;
-        const int tstep = N / (Ns * 4);
-        for (int j = threadIdx.x; j < stride; j += kThreads) {
-            const int k = j & (Ns - 1);
-            float2 v0 = a[j], v1 = a[j + stride], v2 = a[j + 2 * stride], v3 = a[j + 3 * stride];
-            if (Ns > 1) {
-                const float2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
-                if (INV) { v1 = cmulc(v1, w1); v2 = cmulc(v2, w2); v3 = cmulc(v3, w3); }
-                else     { v1 = cmul(v1, w1);  v2 = cmul(v2, w2);  v3 = cmul(v3, w3); }
-            }
-            const float2 s0 = cadd(v0, v2), d0 = csub(v0, v2), s1 = cadd(v1, v3), e = csub(v1, v3);
-            const float2 d1 = INV ? make_float2(-e.y, e.x) : make_float2(e.y, -e.x);   // (+i or -i) * e
-            const int j0 = ((j - k) << 2) + k;
-            b[j0]          = cadd(s0, s1);
-            b[j0 + Ns]     = cadd(d0, d1);
-            b[j0 + 2 * Ns] = csub(s0, s1);
-            b[j0 + 3 * Ns] = csub(d0, d1);
-        }
-        __syncthreads();
-        float2 *t = a; a = b; b = t;
-    }
-    if (Ns < M) {   // one radix-2 stage, Ns == M/2
-        const int stride = M / 2;
-        const int tstep = N / (Ns * 2);
-        for (int j = threadIdx.x; j < stride; j += kThreads) {
-            const int k = j & (Ns - 1);
-            float2 v0 = a[j], v1 = a[j + stride];
-            const float2 w = tw[k * tstep];
-            v1 = INV ? cmulc(v1, w) : cmul(v1, w);
-            const int j0 = ((j - k) << 1) + k;
-            b[j0]      = cadd(v0, v1);
-            b[j0 + Ns] = csub(v0, v1);
-        }
-        __syncthreads();
-        float2 *t = a; a = b; b = t;
-    }
-    return a;
-}
-
-// B real samples (zero padded to N) -> z[n] = x[2n] + i*x[2n+1], n < M.
-template <int M>
-__device__ __forceinline__ void load_block(const float *__restrict__ x, int B, float2 *z)
-{
-    for (int n = threadIdx.x; n < M; n += kThreads) {
-        const int i = 2 * n;
-        z[n] = make_float2(i < B ? x[i] : 0.0f, i + 1 < B ? x[i + 1] : 0.0f);
-    }
-}
-
-// Forward split: Z = FFT_M(z) -> packed spectrum of the N real samples (unnormalised, as
-// performRealOnlyForwardTransform leaves it; reference fp/convolution.cpp:123,144).
-template <int M>
-__device__ __forceinline__ void split_forward(const float2 *Z, float2 *Xp, const float2 *__restrict__ tw)
-{
-    for (int b = threadIdx.x; b < M; b += kThreads) {
-        if (b == 0) {
-            Xp[0] = make_float2(Z[0].x + Z[0].y, Z[0].x - Z[0].y);
-        } else {
-            const float2 p = Z[b], q = Z[M - b];
-            const float2 e = make_float2(0.5f * (p.x + q.x), 0.5f * (p.y - q.y));      // (p + conj q)/2
-            const float2 o = make_float2(0.5f * (p.y + q.y), -0.5f * (p.x - q.x));     // (p - conj q)/(2i)
-            Xp[b] = cadd(e, cmul(tw[b], o));
-        }
-    }
-}
-
-// Inverse split: packed spectrum Y -> Z with IFFT_M(Z)[n] = N * (y[2n] + i*y[2n+1]).
-template <int M>
-__device__ __forceinline__ void split_inverse(const float2 *Y, float2 *Z, const float2 *__restrict__ tw)
-{
-    for (int b = threadIdx.x; b < M; b += kThreads) {
-        if (b == 0) {
-            Z[0] = make_float2(Y[0].x + Y[0].y, Y[0].x - Y[0].y);
-        } else {
-            const float2 p = Y[b], q = Y[M - b];
-            const float2 e = make_float2(p.x + q.x, p.y - q.y);        // p + conj q
-            const float2 d = make_float2(p.x - q.x, p.y + q.y);        // p - conj q
-            const float2 o = cmulc(d, tw[b]);                          // * W_N^{-b}
-            Z[b] = make_float2(e.x - o.y, e.y + o.x);                  // e + i*o
-        }
-    }
-}
-
-// Overlap-add (reference fp/convolution.cpp:209-213): y = N real samples, unscaled, in LDS.
-__device__ __forceinline__ void overlap_add(const float *y, float scale, int B, float *__restrict__ ovl, float *__restrict__ out)
-{
-    for (int i = threadIdx.x; i < B; i += kThreads) {
+    for (int i = lane; i < B; i += kWave) {
         const float o = y[i] * scale + ovl[i];
         ovl[i] = y[B + i] * scale;
         out[i] = o;
@@ -255,50 +160,84 @@ __device__ __forceinline__ void reduce_stripes(const float4 (&acc)[MacGeom<N>::C
 template <int N>
 struct Lds {
     static constexpr int M = N / 2;
-    float2 a[M];
-    float2 b[M];
-    float2 part[MacGeom<N>::STRIPES * M];
+    float2 tw[N / 2];                              // half twiddle table
+    float2 buf[M];                                 // wave 0's FFT buffer; later the summed spectrum Y
+    float2 scratch[MacGeom<N>::STRIPES * M];       // first the new block's spectrum, then the stripe partials
 };
 
 // ---------------------------------------------------------------------------------------------
 // k_step_fused: one workgroup owns one stream for one block step:
 //   input block -> FFT -> ring slot `head`; MAC over all partitions; IFFT; overlap-add; output.
 // grid = S.  The dominant kernel when many streams are batched (HBM-bound, 8*P*N + 16*B bytes).
+// Wave 0 runs the two small FFTs (fft_wave.hpp) while the other waves already stream partitions.
 // ---------------------------------------------------------------------------------------------
-template <int N, int U = 4, bool NT = false>
+template <int N, int U = 2, bool NT = false>
 __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2;
     __shared__ Lds<N> lds;
     const int s = blockIdx.x;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int set = a.set_of_stream[s];
     const int np = a.np_of_set[set];
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
 
-    // older partitions first: their loads do not depend on the new block
+    // issue the small loads now (twiddle half table, and wave 0: the new block) so that their latency
+    // hides under the partition stream; they are parked in registers until the MAC loop is done
+    constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
+    constexpr int ZPL = M > kWave ? M / kWave : 1;
+    float2 twr[TWPT];
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) {
+        const int idx = threadIdx.x + i * kThreads;
+        twr[i] = idx < N / 2 ? a.tw[idx] : make_float2(0.f, 0.f);
+    }
+    float2 zr[ZPL];
+    if (wave == 0) {
+        const float *x = a.in + (size_t) s * a.in_stride;
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = 2 * (lane + i * kWave);
+            zr[i] = make_float2(n < a.B ? x[n] : 0.0f, n + 1 < a.B ? x[n + 1] : 0.0f);
+        }
+    }
+
+    // older partitions: their rows do not depend on the new block
     float4 acc[G::CPT];
 #pragma unroll
     for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
     mac_range<N, U, NT>(H4, X4, 1, np, a.head, a.R, acc, dc);
 
-    // new block: FFT, store into the ring, and its product with partition 0
-    load_block<M>(a.in + (size_t) s * a.in_stride, a.B, lds.a);
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < N / 2) lds.tw[idx] = twr[i];
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = lane + i * kWave;
+            if (n < M) lds.buf[n] = zr[i];
+        }
+    }
     __syncthreads();
-    float2 *Z = fft_lds<M, false>(lds.a, lds.b, a.tw);
-    float2 *Xn = (Z == lds.a) ? lds.b : lds.a;
-    split_forward<M>(Z, Xn, a.tw);
+    if (wave == 0) {      // new block: FFT, packed spectrum to LDS (for partition 0) and into the ring
+        wave_fft<M, false>(lds.buf, lds.tw, lane);
+        float2 *ring = Xs + (size_t) a.head * M;
+        wave_split_forward<M>(lds.buf, lds.tw, lane, [&](int b, float2 v) { lds.scratch[b] = v; ring[b] = v; });
+    }
     __syncthreads();
-    for (int b = threadIdx.x; b < M; b += kThreads) Xs[(size_t) a.head * M + b] = Xn[b];
-    if (np > 0 && threadIdx.x < G::LW) {
+
+    if (np > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
         const int col = threadIdx.x;
 #pragma unroll
         for (int c = 0; c < G::CPT; c++) {
             const float4 h = H4[col + c * G::LW];
-            const float4 x = reinterpret_cast<const float4 *>(Xn)[col + c * G::LW];
+            const float4 x = reinterpret_cast<const float4 *>(lds.scratch)[col + c * G::LW];
             if (c == 0) { dc.x += x.x * h.x; dc.y += x.y * h.y; }
             acc[c].x += x.x * h.x - x.y * h.y;
             acc[c].y += x.x * h.y + x.y * h.x;
@@ -308,13 +247,13 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
     }
     __syncthreads();
 
-    float2 *Y = lds.a;
-    reduce_stripes<N>(acc, dc, lds.part, Y);
-    split_inverse<M>(Y, lds.b, a.tw);
-    __syncthreads();
-    float2 *z = fft_lds<M, true>(lds.b, lds.a, a.tw);
-    overlap_add(reinterpret_cast<const float *>(z), 1.0f / (float) N, a.B,
-                a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride);
+    reduce_stripes<N>(acc, dc, lds.scratch, lds.buf);
+    if (wave == 0) {
+        wave_split_inverse<M>(lds.buf, lds.tw, lane);
+        wave_fft<M, true>(lds.buf, lds.tw, lane);
+        wave_overlap_add(reinterpret_cast<const float *>(lds.buf), 1.0f / (float) N, a.B,
+                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,20 +262,22 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 //   k_cmac_partial    grid = S*splits     partial sums over a contiguous partition range
 //   k_reduce_ifft_ola grid = S            sum of the partials -> IFFT -> overlap-add
 // ---------------------------------------------------------------------------------------------
+// one wave per stream; NF streams per workgroup
 template <int N>
-__global__ __launch_bounds__(kThreads) void k_push_fft(StepArgs a)
+__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft(StepArgs a, int S)
 {
-    constexpr int M = N / 2;
-    __shared__ float2 la[M], lb[M];
-    const int s = blockIdx.x;
-    load_block<M>(a.in + (size_t) s * a.in_stride, a.B, la);
+    constexpr int M = N / 2, NF = FftGeom<N>::NF;
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int s = blockIdx.x * NF + wave;
+    stage_twiddles<N>(a.tw, l_tw);
+    if (s < S) wave_load_block<M>(a.in + (size_t) s * a.in_stride, a.B, l_buf[wave], lane);
     __syncthreads();
-    float2 *Z = fft_lds<M, false>(la, lb, a.tw);
-    float2 *Xn = (Z == la) ? lb : la;
-    split_forward<M>(Z, Xn, a.tw);
-    __syncthreads();
+    if (s >= S) return;
+    wave_fft<M, false>(l_buf[wave], l_tw, lane);
     float2 *dst = a.X + ((size_t) s * a.R + a.head) * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Xn[b];
+    wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
 }
 
 template <int N>
@@ -362,26 +303,65 @@ __global__ __launch_bounds__(kThreads) void k_cmac_partial(StepArgs a)
     for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Y[b];
 }
 
+// sum of `nrows` partial spectra (rows of M float2, row r at src + r*M) by the whole workgroup:
+// stripes take interleaved rows with 4 loads in flight, then combine through LDS.  Result in Y (LDS).
+template <int N>
+__device__ __forceinline__ void sum_partials(const float2 *__restrict__ src, int nrows, float2 *part, float2 *Y)
+{
+    using G = MacGeom<N>;
+    const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll 1
+    for (int c = 0; c < G::CPT; c++) {
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+        int r = stripe;
+        for (; r + 3 * G::STRIPES < nrows; r += 4 * G::STRIPES) {
+            const float4 v0 = src4[(size_t) r * G::L + col + c * G::LW];
+            const float4 v1 = src4[(size_t) (r + G::STRIPES) * G::L + col + c * G::LW];
+            const float4 v2 = src4[(size_t) (r + 2 * G::STRIPES) * G::L + col + c * G::LW];
+            const float4 v3 = src4[(size_t) (r + 3 * G::STRIPES) * G::L + col + c * G::LW];
+            t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
+            t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+            t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
+            t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
+        }
+        for (; r < nrows; r += G::STRIPES) {
+            const float4 v0 = src4[(size_t) r * G::L + col + c * G::LW];
+            t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
+        }
+        const float4 t = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y),
+                                     (t0.z + t1.z) + (t2.z + t3.z), (t0.w + t1.w) + (t2.w + t3.w));
+        reinterpret_cast<float4 *>(part)[stripe * G::L + col + c * G::LW] = t;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < G::M; b += kThreads) {
+        float2 v = part[b];
+#pragma unroll
+        for (int t = 1; t < G::STRIPES; t++) v = cadd(v, part[t * G::M + b]);
+        Y[b] = v;
+    }
+    __syncthreads();
+}
+
 template <int N>
 __global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
 {
+    using G = MacGeom<N>;
     constexpr int M = N / 2;
-    __shared__ float2 la[M], lb[M];
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[M];
+    __shared__ float2 l_part[G::STRIPES * M];
     const int s = blockIdx.x;
-    const float2 *src = a.part + (size_t) s * a.splits * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) {
-        float2 v = src[b];
-        for (int j = 1; j < a.splits; j++) v = cadd(v, src[(size_t) j * M + b]);
-        la[b] = v;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    stage_twiddles<N>(a.tw, l_tw);
+    sum_partials<N>(a.part + (size_t) s * a.splits * M, a.splits, l_part, l_buf);   // ends with a barrier (covers l_tw)
+    if (wave == 0) {
+        wave_split_inverse<M>(l_buf, l_tw, lane);
+        wave_fft<M, true>(l_buf, l_tw, lane);
+        wave_overlap_add(reinterpret_cast<const float *>(l_buf), 1.0f / (float) N, a.B,
+                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
     }
-    __syncthreads();
-    split_inverse<M>(la, lb, a.tw);
-    __syncthreads();
-    float2 *z = fft_lds<M, true>(lb, la, a.tw);
-    overlap_add(reinterpret_cast<const float *>(z), 1.0f / (float) N, a.B,
-                a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Time-tiled path: a call that carries T > 1 new blocks per stream (host blocks larger than B, or the
@@ -396,21 +376,24 @@ __global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
 //   k_ifft_ola_batch   grid = S*T: sums the nq partials of block j and of block j-1 (for its tail)
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kThreads) void k_push_fft_batch(StepArgs a)
+__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepArgs a, int S)
 {
-    constexpr int M = N / 2;
-    __shared__ float2 la[M], lb[M];
-    const int j = blockIdx.x % a.T, s = blockIdx.x / a.T;
-    load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, la);
+    constexpr int M = N / 2, NF = FftGeom<N>::NF;
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int item = blockIdx.x * NF + wave;
+    const bool live = item < S * a.T;
+    const int j = item % a.T, s = item / a.T;
+    stage_twiddles<N>(a.tw, l_tw);
+    if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
     __syncthreads();
-    float2 *Z = fft_lds<M, false>(la, lb, a.tw);
-    float2 *Xn = (Z == la) ? lb : la;
-    split_forward<M>(Z, Xn, a.tw);
-    __syncthreads();
+    if (!live) return;
+    wave_fft<M, false>(l_buf[wave], l_tw, lane);
     int slot = a.head + j;
     if (slot >= a.R) slot -= a.R;
     float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Xn[b];
+    wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
 }
 
 // XCD-aware workgroup id: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
@@ -502,70 +485,105 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
     }
 }
 
+// one wave: sum the nq partial rows of one output block into buf (LDS)
 template <int N>
-__global__ __launch_bounds__(kThreads) void k_ifft_ola_batch(StepArgs a)
+__device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, int nq, float2 *buf, int lane)
 {
-    constexpr int M = N / 2;
-    __shared__ float2 la[M], lb[M];
-    __shared__ float tail[M];             // B <= N/2 = M
-    const int j = blockIdx.x % a.T, s = blockIdx.x / a.T;
-    const float scale = 1.0f / (float) N;
-    // tail of the previous block of this call, or the saved overlap for the first block
-    if (j > 0) {
-        const float2 *src = a.part + ((size_t) s * a.T + (j - 1)) * a.nq * M;
-        for (int b = threadIdx.x; b < M; b += kThreads) {
-            float2 v = src[b];
-            for (int q = 1; q < a.nq; q++) v = cadd(v, src[(size_t) q * M + b]);
-            la[b] = v;
+    constexpr int M = N / 2, L = M / 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    for (int c = lane; c < L; c += kWave) {
+        float4 v = src4[c];
+        int q = 1;
+        for (; q + 3 < nq; q += 4) {      // four independent loads in flight
+            const float4 w0 = src4[(size_t) q * L + c], w1 = src4[(size_t) (q + 1) * L + c];
+            const float4 w2 = src4[(size_t) (q + 2) * L + c], w3 = src4[(size_t) (q + 3) * L + c];
+            v.x += (w0.x + w1.x) + (w2.x + w3.x); v.y += (w0.y + w1.y) + (w2.y + w3.y);
+            v.z += (w0.z + w1.z) + (w2.z + w3.z); v.w += (w0.w + w1.w) + (w2.w + w3.w);
         }
-        __syncthreads();
-        split_inverse<M>(la, lb, a.tw);
-        __syncthreads();
-        const float *y = reinterpret_cast<const float *>(fft_lds<M, true>(lb, la, a.tw));
-        for (int i = threadIdx.x; i < a.B; i += kThreads) tail[i] = y[a.B + i] * scale;
+        for (; q < nq; q++) {
+            const float4 w = src4[(size_t) q * L + c];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        reinterpret_cast<float4 *>(buf)[c] = v;
+    }
+    wave_sync();
+}
+
+// one wave per output block (s, j): IFFT of block j-1 for its tail (or the saved overlap for j = 0),
+// IFFT of block j, overlap-add; the wave of the last block also saves the new overlap.
+template <int N>
+__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ifft_ola_batch(StepArgs a, int S)
+{
+    constexpr int M = N / 2, NF = FftGeom<N>::NF;
+    constexpr int VPL = M > kWave ? M / kWave : 1;     // tail samples per lane (B <= M)
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int item = blockIdx.x * NF + wave;
+    stage_twiddles<N>(a.tw, l_tw);
+    __syncthreads();
+    if (item >= S * a.T) return;
+    const int j = item % a.T, s = item / a.T;
+    const float scale = 1.0f / (float) N;
+    float2 *buf = l_buf[wave];
+    const float *y = reinterpret_cast<const float *>(buf);
+    float tail[VPL];
+    if (j > 0) {
+        wave_sum_rows<N>(a.part + ((size_t) s * a.T + (j - 1)) * a.nq * M, a.nq, buf, lane);
+        wave_split_inverse<M>(buf, l_tw, lane);
+        wave_fft<M, true>(buf, l_tw, lane);
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int n = lane + i * kWave;
+            tail[i] = n < a.B ? y[a.B + n] * scale : 0.0f;
+        }
+        wave_sync();
     } else {
         const float *ov = a.ovl + (size_t) s * a.B;
-        for (int i = threadIdx.x; i < a.B; i += kThreads) tail[i] = ov[i];
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int n = lane + i * kWave;
+            tail[i] = n < a.B ? ov[n] : 0.0f;
+        }
     }
-    __syncthreads();
-    const float2 *src = a.part + ((size_t) s * a.T + j) * a.nq * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) {
-        float2 v = src[b];
-        for (int q = 1; q < a.nq; q++) v = cadd(v, src[(size_t) q * M + b]);
-        la[b] = v;
-    }
-    __syncthreads();
-    split_inverse<M>(la, lb, a.tw);
-    __syncthreads();
-    const float *y = reinterpret_cast<const float *>(fft_lds<M, true>(lb, la, a.tw));
+    wave_sum_rows<N>(a.part + ((size_t) s * a.T + j) * a.nq * M, a.nq, buf, lane);
+    wave_split_inverse<M>(buf, l_tw, lane);
+    wave_fft<M, true>(buf, l_tw, lane);
     float *out = a.out + (size_t) s * a.out_stride + (size_t) j * a.B;
-    for (int i = threadIdx.x; i < a.B; i += kThreads) out[i] = y[i] * scale + tail[i];
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int n = lane + i * kWave;
+        if (n < a.B) out[n] = y[n] * scale + tail[i];
+    }
     if (j == a.T - 1) {
         float *on = a.ovl_next + (size_t) s * a.B;
-        for (int i = threadIdx.x; i < a.B; i += kThreads) on[i] = y[a.B + i] * scale;
+        for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ir_fft: IR partitions -> spectra (reference fp/convolution.cpp:106-125).  grid = (P, n_rows):
+// k_ir_fft: IR partitions -> spectra (reference fp/convolution.cpp:106-125).  one wave per partition:
 // row r of `ir` (time domain, [n_rows][P*B], zero padded) -> H set first_set + r.
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kThreads) void k_ir_fft(const float *__restrict__ ir, float2 *__restrict__ H,
-                                                     const float2 *__restrict__ tw, int B, int P, int first_set,
-                                                     int first_partition)
+__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *__restrict__ ir, float2 *__restrict__ H,
+                                                                   const float2 *__restrict__ tw, int B, int P, int first_set,
+                                                                   int first_partition, int nparts, int nrows)
 {
-    constexpr int M = N / 2;
-    __shared__ float2 la[M], lb[M];
-    const int k = blockIdx.x, r = blockIdx.y;
-    load_block<M>(ir + ((size_t) r * gridDim.x + k) * B, B, la);
+    constexpr int M = N / 2, NF = FftGeom<N>::NF;
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int item = blockIdx.x * NF + wave;
+    const bool live = item < nparts * nrows;
+    const int k = item % nparts, r = item / nparts;
+    stage_twiddles<N>(tw, l_tw);
+    if (live) wave_load_block<M>(ir + ((size_t) r * nparts + k) * B, B, l_buf[wave], lane);
     __syncthreads();
-    float2 *Z = fft_lds<M, false>(la, lb, tw);
-    float2 *Xn = (Z == la) ? lb : la;
-    split_forward<M>(Z, Xn, tw);
-    __syncthreads();
+    if (!live) return;
+    wave_fft<M, false>(l_buf[wave], l_tw, lane);
     float2 *dst = H + ((size_t) (first_set + r) * P + first_partition + k) * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Xn[b];
+    wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
 }
 
 }  // namespace irb

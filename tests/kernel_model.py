@@ -92,3 +92,84 @@ def cmul_packed(a, c):
     out = (a * c).astype(np.complex64)
     out[0] = np.complex64(complex(a[0].real * c[0].real, a[0].imag * c[0].imag))
     return out
+
+
+# ---- model of fft_wave.hpp: one wave per transform, IN PLACE (all lanes read, then all lanes write),
+# ---- half twiddle table with sign symmetry, split passes that handle bins b and M-b in one lane
+
+def half_table(N):
+    return twiddle_table(N)[:N // 2]
+
+
+def tw_half(ht, N, i):
+    w = ht[i & (N // 2 - 1)]
+    return -w if (i & (N // 2)) else w
+
+
+def wave_fft(buf, ht, N, inverse=False, lanes=64):
+    M = len(buf)
+    buf = buf.astype(np.complex64).copy()
+    Ns = 1
+    while Ns < M:
+        R = 4 if Ns * 4 <= M else 2
+        nb = M // R
+        tstep = N // (Ns * R)
+        reads = {}
+        for lane in range(lanes):                       # phase 1: every lane reads all its points
+            for j in range(lane, nb, lanes):
+                reads[j] = [buf[j + r * nb] for r in range(R)]
+        for j, v in reads.items():                      # phase 2: butterflies + in-place writes
+            k = j & (Ns - 1)
+            for r in range(1, R):
+                w = tw_half(ht, N, k * r * tstep)
+                v[r] = np.complex64(v[r] * (np.conj(w) if inverse else w))
+            if R == 4:
+                s0, d0, s1, e = v[0] + v[2], v[0] - v[2], v[1] + v[3], v[1] - v[3]
+                d1 = e * (1j if inverse else -1j)
+                o = [s0 + s1, d0 + d1, s0 - s1, d0 - d1]
+            else:
+                o = [v[0] + v[1], v[0] - v[1]]
+            j0 = (j - k) * R + k
+            for r in range(R):
+                buf[j0 + r * Ns] = np.complex64(o[r])
+        Ns *= R
+    return buf
+
+
+def wave_rfft_packed(x, N, ht):
+    M = N // 2
+    Z = wave_fft((x[0::2] + 1j * x[1::2]).astype(np.complex64), ht, N)
+    X = np.empty(M, np.complex64)
+    for b in range(M // 2 + 1):
+        if b == 0:
+            X[0] = np.complex64(complex(Z[0].real + Z[0].imag, Z[0].real - Z[0].imag))
+        else:
+            p, q = Z[b], Z[M - b]
+            e = np.complex64(complex(0.5 * (p.real + q.real), 0.5 * (p.imag - q.imag)))
+            o = np.complex64(complex(0.5 * (p.imag + q.imag), -0.5 * (p.real - q.real)))
+            t = np.complex64(tw_half(ht, N, b) * o)
+            X[b] = np.complex64(e + t)
+            if b != M - b:
+                X[M - b] = np.complex64(complex(e.real - t.real, t.imag - e.imag))
+    return X
+
+
+def wave_irfft_packed(Y, N, ht):
+    M = N // 2
+    Z = Y.astype(np.complex64).copy()
+    for b in range(M // 2 + 1):
+        if b == 0:
+            Z[0] = np.complex64(complex(Y[0].real + Y[0].imag, Y[0].real - Y[0].imag))
+        else:
+            p, q = Y[b], Y[M - b]
+            e = complex(p.real + q.real, p.imag - q.imag)
+            d = np.complex64(complex(p.real - q.real, p.imag + q.imag))
+            o = np.complex64(d * np.conj(tw_half(ht, N, b)))
+            Z[b] = np.complex64(complex(e.real - o.imag, e.imag + o.real))
+            if b != M - b:
+                Z[M - b] = np.complex64(complex(e.real + o.imag, o.real - e.imag))
+    z = wave_fft(Z, ht, N, inverse=True) * np.float32(1.0 / N)
+    y = np.empty(N, np.float32)
+    y[0::2] = z.real
+    y[1::2] = z.imag
+    return y

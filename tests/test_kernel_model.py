@@ -23,3 +23,20 @@ def test_model(N):
     y = irfft_packed(cmul_packed(X, rfft_packed(h, N, tw)), N, tw)
     ref = np.fft.irfft(np.fft.rfft(x.astype(np.float64)) * np.fft.rfft(h.astype(np.float64)))
     assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_wave_model(N):
+    """fft_wave.hpp: in-place one-wave transform, half twiddle table, paired split passes."""
+    from kernel_model import half_table, wave_fft, wave_irfft_packed, wave_rfft_packed
+    rng = np.random.default_rng(N + 1)
+    ht, M = half_table(N), N // 2
+    z = (rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex64)
+    tol = 4e-7 * N
+    assert np.abs(wave_fft(z, ht, N) - np.fft.fft(z.astype(np.complex128))).max() < tol
+    assert np.abs(wave_fft(z, ht, N, True) - np.fft.ifft(z.astype(np.complex128)) * M).max() < tol
+    x = rng.standard_normal(N).astype(np.float32)
+    X, R = wave_rfft_packed(x, N, ht), np.fft.rfft(x.astype(np.float64))
+    assert np.abs(X[1:] - R[1:M]).max() < tol
+    assert abs(X[0].real - R[0].real) < tol and abs(X[0].imag - R[M].real) < tol
+    assert np.abs(wave_irfft_packed(X, N, ht) - x).max() < 2e-6
