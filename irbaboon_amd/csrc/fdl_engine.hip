@@ -92,6 +92,7 @@ int dev_alloc(irb_fdl *h, T **p, size_t n)
 int choose_splits(const irb_fdl *h)
 {
     if (h->flags & IRB_FDL_FORCE_FUSED) return 1;
+    if (const char *v = std::getenv("IRB_SPLITS")) return std::max(1, std::atoi(v));    // tuning override
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     const int by_work = (h->P + stripes * 4 - 1) / (stripes * 4);       // >= 4 rows per stripe and workgroup
     if (h->flags & IRB_FDL_FORCE_SPLIT) return std::max(2, std::min(by_work, 64));
@@ -111,7 +112,8 @@ int tiled_splits(const irb_fdl *h, int T)
     const int ntiles = (T + kTT - 1) / kTT;
     const int by_work = std::max(1, (h->Ppad / kTT) / (stripes * 2));
     const long wgs = (long) h->S * ntiles;
-    const int by_chip = (int) std::max<long>(1, (1024 + wgs - 1) / wgs);
+    const int by_chip = (int) std::max<long>(1, (768 + wgs - 1) / wgs);
+    if (const char *v = std::getenv("IRB_TILED_SPLITS")) return std::max(1, std::min(by_work, std::atoi(v)));   // tuning override
     return std::max(1, std::min(by_work, by_chip));
 }
 
