@@ -1,0 +1,64 @@
+/*
+ * irb_deconv.h -- C ABI of the config-5 chain (libirbfdl.so): the exp-sine-sweep deconvolution path of
+ * Flixor/IRBaboon.  Large real FFTs and the spectral division run on the MI355X; the fractional-octave
+ * smoothing and the half swap are host code (the north star keeps fp::ir IR preparation on the host).
+ * Same conventions as irb_fdl.h (error codes, irb_last_error()).  Paths are relative to the reference.
+ *
+ * Spectrum layout = the reference's: a buffer of 2N floats, interleaved (re, im) for bins 0..N/2
+ * (Nyquist at float index N), unnormalised forward, inverse scaled by 1/N (fp/tools.cpp:321-369).
+ */
+#ifndef IRB_DECONV_H
+#define IRB_DECONV_H
+
+#include "irb_fdl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct irb_lfft irb_lfft;     /* plan for one FFT length, device resident */
+
+/* Replaces: tools::nextPowerOfTwo (fp/tools.cpp:180-196). */
+int  irb_next_power_of_two(int x);
+
+/* Replaces: tools::fftTransform(buffer) (fp/tools.cpp:321-346): len host samples -> out[2N],
+ * N = nextPowerOfTwo(len) (channel 0 only, as the reference copies, :328).  len >= 17. */
+int  irb_fft_transform(int device, const float *in, int len, float *out);
+
+/* Replaces: tools::fftInvTransform(buffer) (fp/tools.cpp:351-369): in[fft_size = 2N] -> out[N]. */
+int  irb_fft_inv_transform(int device, const float *in, int fft_size, float *out);
+
+/* Replaces: convolution::averagingFilter (fp/convolution.cpp:406-546), one channel, in place, HOST code. */
+void irb_averaging_filter(float *buffer, int fft_size, double octave_fraction, double sample_rate,
+                          int log_avg, int include_phase, int include_amplitude);
+
+/* Replaces: ir::shifteroo (fp/ir.cpp:85-103), HOST code. */
+void irb_shifteroo(float *buffer, int n);
+
+/* Replaces: convolution::deconvolve(numerator, denominator, sampleRate, smoothing, includePhase,
+ * includeAmplitude) (fp/convolution.cpp:351-403): mono, the shorter buffer zero extended, FFT length
+ * N = nextPowerOfTwo(max length) with no further padding (so the division is circular), zero
+ * denominators skipped (fp/tools.cpp:74-77), three 1/13-octave smoothing passes when `smoothing`,
+ * half swap when !include_phase.  out must hold N samples (out_len >= N). */
+int  irb_deconvolve(int device, const float *num, int len_num, const float *den, int len_den,
+                    double sample_rate, int smoothing, int include_phase, int include_amplitude,
+                    float *out, int out_len);
+
+/* Replaces: ir::invertFilter(buffer, sampleRate) (fp/ir.cpp:13-18). */
+int  irb_invert_filter(int device, const float *ir, int len, int sample_rate, float *out, int out_len);
+
+/* ---- reusable plan with device-resident buffers (bench, repeated transforms) ---- */
+int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
+void irb_lfft_destroy(irb_lfft *p);
+/* scratch owned by the plan: d_time [max_batch][N] floats, d_spec [max_batch][2N] floats */
+int  irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec);
+int  irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int batch);   /* asynchronous */
+int  irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int batch);  /* asynchronous */
+int  irb_lfft_synchronize(irb_lfft *p);
+int  irb_lfft_mark(irb_lfft *p, int slot);
+int  irb_lfft_elapsed_ms(irb_lfft *p, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

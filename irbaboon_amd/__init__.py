@@ -5,3 +5,5 @@ from ._lib import IrbError, lib                     # noqa: F401
 from .convolution import ChannelLayout, convolvePeriodic   # noqa: F401
 from .engine import FdlEngine                       # noqa: F401
 from .rt import RtConvolver                         # noqa: F401
+from .deconvolution import (LargeFft, averagingFilter, deconvolve, fftInvTransform,   # noqa: F401,E402
+                            fftTransform, invertFilter, nextPowerOfTwo, shifteroo)

@@ -35,7 +35,7 @@ class FdlInfo(C.Structure):
                 ("algorithmic_bytes_per_block_step", C.c_double)]
 
 
-# every symbol include/irb_fdl.h declares: (name, restype, argtypes)
+# every symbol include/irb_fdl.h and include/irb_deconv.h declare: (name, restype, argtypes)
 SYMBOLS = [
     ("irb_fdl_create", C.c_int, [C.POINTER(FdlConfig), C.POINTER(C.c_void_p)]),
     ("irb_fdl_destroy", None, [C.c_void_p]),
@@ -60,6 +60,22 @@ SYMBOLS = [
     ("irb_rt_process_block", C.c_int, [C.c_void_p, fpp, C.c_int]),
     ("irb_rt_latency", C.c_int, [C.c_void_p]),
     ("irb_rt_partitions", C.c_int, [C.c_void_p]),
+    # include/irb_deconv.h
+    ("irb_next_power_of_two", C.c_int, [C.c_int]),
+    ("irb_fft_transform", C.c_int, [C.c_int, fp, C.c_int, fp]),
+    ("irb_fft_inv_transform", C.c_int, [C.c_int, fp, C.c_int, fp]),
+    ("irb_averaging_filter", None, [fp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+    ("irb_shifteroo", None, [fp, C.c_int]),
+    ("irb_deconvolve", C.c_int, [C.c_int, fp, C.c_int, fp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, fp, C.c_int]),
+    ("irb_invert_filter", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int]),
+    ("irb_lfft_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("irb_lfft_destroy", None, [C.c_void_p]),
+    ("irb_lfft_buffers", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("irb_lfft_forward_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("irb_lfft_inverse_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("irb_lfft_synchronize", C.c_int, [C.c_void_p]),
+    ("irb_lfft_mark", C.c_int, [C.c_void_p, C.c_int]),
+    ("irb_lfft_elapsed_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("irb_last_error", C.c_char_p, []),
     ("irb_version", C.c_char_p, []),
 ]

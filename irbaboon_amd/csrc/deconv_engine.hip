@@ -1,0 +1,414 @@
+// deconv_engine.hip -- host side of the config-5 chain: large real FFT plans (irb_lfft_*), the one-shot
+// mirrors of tools::fftTransform / fftInvTransform (reference fp/tools.cpp:321-369), convolution::deconvolve
+// (fp/convolution.cpp:351-403), ir::invertFilter (fp/ir.cpp:13-18), and the host-resident IR preparation the
+// north star keeps on the CPU: convolution::averagingFilter (fp/convolution.cpp:406-546) and ir::shifteroo
+// (fp/ir.cpp:85-103).  The transforms and the spectral division run on the GPU; there is no CPU fallback
+// for them.
+#include "../../include/irb_deconv.h"
+#include "lfft_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+extern "C" int irb_set_error_(int code, const char *msg);   // fdl_engine.hip
+
+namespace {
+
+int failf(int code, const char *fmt, const char *what, const char *detail)
+{
+    char msg[400];
+    std::snprintf(msg, sizeof msg, fmt, what, detail);
+    return irb_set_error_(code, msg);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return failf(IRB_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+bool is_pow2(int x) { return x != 0 && (x & (x - 1)) == 0; }
+int ilog2(int x) { int l = 0; while ((1 << (l + 1)) <= x) l++; return l; }
+
+std::vector<float2> root_table(int root, int count, int stride)      // W_root^(i*stride), i < count, in double
+{
+    std::vector<float2> t((size_t) std::max(count, 1));
+    for (int i = 0; i < count; i++) {
+        const double ph = -2.0 * 3.14159265358979323846 * (double) i * (double) stride / (double) root;
+        t[i] = make_float2((float) std::cos(ph), (float) std::sin(ph));
+    }
+    return t;
+}
+
+}  // namespace
+
+struct irb_lfft {
+    int device = 0, N = 0, M = 0, M1 = 0, M2 = 0, max_batch = 1, logE = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tabA = nullptr, *d_tabB = nullptr;
+    float2 *d_w0 = nullptr, *d_w1 = nullptr;     // complex work buffers [max_batch][M]
+    float *d_time = nullptr, *d_spec = nullptr;  // [max_batch][N] samples, [max_batch][2N] spectrum (one-shot API)
+};
+
+namespace {
+
+#define FOR_M(M_, ...)                                                       \
+    switch (M_) {                                                            \
+    case 16:   { constexpr int MM = 16;   __VA_ARGS__; } break;              \
+    case 32:   { constexpr int MM = 32;   __VA_ARGS__; } break;              \
+    case 64:   { constexpr int MM = 64;   __VA_ARGS__; } break;              \
+    case 128:  { constexpr int MM = 128;  __VA_ARGS__; } break;              \
+    case 256:  { constexpr int MM = 256;  __VA_ARGS__; } break;              \
+    case 512:  { constexpr int MM = 512;  __VA_ARGS__; } break;              \
+    case 1024: { constexpr int MM = 1024; __VA_ARGS__; } break;              \
+    case 2048: { constexpr int MM = 2048; __VA_ARGS__; } break;              \
+    default: return irb_set_error_(IRB_ERR_ARG, "unsupported FFT factor");   \
+    }
+
+irb::LfftArgs args_of(const irb_lfft *p, int batch)
+{
+    irb::LfftArgs a;
+    a.tw1 = p->d_tw1; a.tw2 = p->d_tw2; a.tabA = p->d_tabA; a.tabB = p->d_tabB; a.logE = p->logE;
+    a.N = p->N; a.M = p->M; a.M1 = p->M1; a.M2 = p->M2; a.batch = batch;
+    return a;
+}
+
+// complex M-point transform of `batch` items: src -> dst (dst may equal neither work buffer's alias of src)
+template <bool INV>
+int complex_fft(irb_lfft *p, const float2 *src, float2 *tmp, float2 *dst, int batch)
+{
+    const irb::LfftArgs a = args_of(p, batch);
+    if (p->M2 == 1) {
+        FOR_M(p->M1, {
+            constexpr int NF = irb::WaveGeom<MM>::NF;
+            irb::k_lfft_small<MM, INV><<<dim3((batch + NF - 1) / NF), dim3(irb::kWave * NF), 0, p->stream>>>(a, src, dst);
+        });
+    } else {
+        FOR_M(p->M1, {
+            constexpr int NF = irb::WaveGeom<MM>::NF;
+            const long items = (long) batch * p->M2;
+            irb::k_lfft_cols<MM, INV><<<dim3((unsigned) ((items + NF - 1) / NF)), dim3(irb::kWave * NF), 0, p->stream>>>(a, src, tmp);
+        });
+        FOR_M(p->M2, {
+            constexpr int NF = irb::WaveGeom<MM>::NF;
+            const long items = (long) batch * p->M1;
+            irb::k_lfft_rows<MM, INV><<<dim3((unsigned) ((items + NF - 1) / NF)), dim3(irb::kWave * NF), 0, p->stream>>>(a, tmp, dst);
+        });
+    }
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int irb_next_power_of_two(int x)                       // tools::nextPowerOfTwo, fp/tools.cpp:180-196
+{
+    if (is_pow2(x)) return x;
+    int r = 1;
+    while (r <= x) r *= 2;
+    return r;
+}
+
+void irb_lfft_destroy(irb_lfft *p)
+{
+    if (!p) return;
+    (void) hipSetDevice(p->device);
+    if (p->stream) (void) hipStreamSynchronize(p->stream);
+    (void) hipFree(p->d_tw1); (void) hipFree(p->d_tw2); (void) hipFree(p->d_tabA); (void) hipFree(p->d_tabB);
+    (void) hipFree(p->d_w0); (void) hipFree(p->d_w1); (void) hipFree(p->d_time); (void) hipFree(p->d_spec);
+    for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
+    if (p->stream) (void) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
+{
+    if (!out) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (!is_pow2(fft_len) || fft_len < 32 || fft_len > (1 << 23))
+        return irb_set_error_(IRB_ERR_ARG, "fft_len must be a power of two in [32, 2^23]");
+    if (max_batch < 1) return irb_set_error_(IRB_ERR_ARG, "max_batch must be >= 1");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return irb_set_error_(IRB_ERR_HIP, "HIP device not present");
+    HIP_TRY(hipSetDevice(device));
+    irb_lfft *p = new (std::nothrow) irb_lfft;
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "out of host memory");
+    p->device = device; p->N = fft_len; p->M = fft_len / 2; p->max_batch = max_batch;
+    const int m = ilog2(p->M);
+    if (p->M <= 2048) { p->M1 = p->M; p->M2 = 1; }
+    else { p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1; }
+    p->logE = std::min(10, ilog2(p->N));
+    const int E = 1 << p->logE;
+    int rc = IRB_OK;
+    do {
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreate(&p->ev[0])) != hipSuccess || (e = hipEventCreate(&p->ev[1])) != hipSuccess) {
+            rc = failf(IRB_ERR_HIP, "%s: %s", "stream/event create", hipGetErrorString(e)); break;
+        }
+        const auto t1 = root_table(2 * p->M1, p->M1, 1), t2 = root_table(2 * p->M2, p->M2, 1);
+        const auto tA = root_table(p->N, p->N / E, E), tB = root_table(p->N, E, 1);
+        const size_t cw = sizeof(float2) * (size_t) max_batch * p->M;
+        if ((e = hipMalloc(&p->d_tw1, sizeof(float2) * t1.size())) != hipSuccess ||
+            (e = hipMalloc(&p->d_tw2, sizeof(float2) * t2.size())) != hipSuccess ||
+            (e = hipMalloc(&p->d_tabA, sizeof(float2) * tA.size())) != hipSuccess ||
+            (e = hipMalloc(&p->d_tabB, sizeof(float2) * tB.size())) != hipSuccess ||
+            (e = hipMalloc(&p->d_w0, cw)) != hipSuccess || (e = hipMalloc(&p->d_w1, cw)) != hipSuccess ||
+            (e = hipMalloc(&p->d_time, sizeof(float) * (size_t) max_batch * p->N)) != hipSuccess ||
+            (e = hipMalloc(&p->d_spec, sizeof(float) * (size_t) max_batch * 2 * p->N)) != hipSuccess ||
+            (e = hipMemcpy(p->d_tw1, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->d_tw2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->d_tabA, tA.data(), sizeof(float2) * tA.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(p->d_tabB, tB.data(), sizeof(float2) * tB.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+            rc = failf(IRB_ERR_HIP, "%s: %s", "plan allocation", hipGetErrorString(e)); break;
+        }
+    } while (0);
+    if (rc != IRB_OK) { irb_lfft_destroy(p); return rc; }
+    *out = p;
+    return IRB_OK;
+}
+
+// d_in: [batch][N] real samples (already zero padded); d_spec: [batch][2N] floats, reference layout
+int irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int batch)
+{
+    if (!p || !d_in || !d_spec) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = complex_fft<false>(p, reinterpret_cast<const float2 *>(d_in), p->d_w0, p->d_w1, batch);
+    if (rc != IRB_OK) return rc;
+    const long work = (long) batch * (p->M / 2 + 1);
+    irb::k_rsplit_fwd<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(args_of(p, batch), p->d_w1, d_spec);
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+// d_spec: [batch][2N] floats (bins 0..N/2 used); d_out: [batch][N] samples, scaled 1/N
+int irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int batch)
+{
+    if (!p || !d_spec || !d_out) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
+    HIP_TRY(hipSetDevice(p->device));
+    const long work = (long) batch * (p->M / 2 + 1);
+    irb::k_rsplit_inv<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(args_of(p, batch), d_spec, p->d_w0);
+    HIP_TRY(hipGetLastError());
+    float2 *dst = (p->M2 == 1) ? p->d_w1 : p->d_w0;          // four-step: w0 -> w1 -> w0 ; small: w0 -> w1
+    int rc = complex_fft<true>(p, p->d_w0, p->d_w1, dst, batch);
+    if (rc != IRB_OK) return rc;
+    const long n = (long) batch * p->N;
+    irb::k_scale_real<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, p->stream>>>(reinterpret_cast<const float *>(dst), d_out, n, 1.0f / (float) p->N);
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+int irb_lfft_synchronize(irb_lfft *p)
+{
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return IRB_OK;
+}
+
+int irb_lfft_mark(irb_lfft *p, int slot)
+{
+    if (!p || slot < 0 || slot > 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev[slot], p->stream));
+    return IRB_OK;
+}
+
+int irb_lfft_elapsed_ms(irb_lfft *p, float *ms)
+{
+    if (!p || !ms) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms, p->ev[0], p->ev[1]));
+    return IRB_OK;
+}
+
+int irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec)
+{
+    if (!p || !d_time || !d_spec) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    *d_time = p->d_time; *d_spec = p->d_spec;
+    return IRB_OK;
+}
+
+// ---- tools::fftTransform (fp/tools.cpp:321-346, formatAmplPhase = false) -------------------------------
+int irb_fft_transform(int device, const float *in, int len, float *out)
+{
+    if (!in || !out || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    const int N = std::max(32, irb_next_power_of_two(len));
+    if (N != irb_next_power_of_two(len)) return irb_set_error_(IRB_ERR_ARG, "buffers shorter than 17 samples are not supported");
+    irb_lfft *p = nullptr;
+    int rc = irb_lfft_create(device, N, 1, &p);
+    if (rc != IRB_OK) return rc;
+    hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * N, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_time, in, sizeof(float) * len, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) { rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, 1); }
+    if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_spec, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "irb_fft_transform", hipGetErrorString(e));
+    irb_lfft_destroy(p);
+    return rc;
+}
+
+// ---- tools::fftInvTransform (fp/tools.cpp:351-369): fft_size = 2N floats in, N samples out --------------
+int irb_fft_inv_transform(int device, const float *in, int fft_size, float *out)
+{
+    if (!in || !out || fft_size < 64 || !is_pow2(fft_size)) return irb_set_error_(IRB_ERR_ARG, "fft_size must be a power of two >= 64");
+    const int N = fft_size / 2;
+    irb_lfft *p = nullptr;
+    int rc = irb_lfft_create(device, N, 1, &p);
+    if (rc != IRB_OK) return rc;
+    hipError_t e = hipMemcpyAsync(p->d_spec, in, sizeof(float) * fft_size, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, 1);
+    if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_time, sizeof(float) * N, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "irb_fft_inv_transform", hipGetErrorString(e));
+    irb_lfft_destroy(p);
+    return rc;
+}
+
+// ---- host-resident IR preparation ----------------------------------------------------------------------
+
+static void round_to_zero(float *x, float threshold)               // fp/tools.cpp:199-209
+{
+    if (threshold < 0.0f) return;
+    if (!std::signbit(*x) && *x < threshold) *x = 0.0f;
+    if (std::signbit(*x) && *x > -(threshold)) *x = 0.0f;
+}
+
+static void round_to_1e16(float *x)                                 // fp/tools.cpp:213-218
+{
+    if (!std::signbit(*x) && *x < 1e-16) *x = 1e-16;
+    if (std::signbit(*x) && *x > -1e-16) *x = -1e-16;
+}
+
+// convolution::averagingFilter (fp/convolution.cpp:406-546), one channel, in place.  Sequential float
+// running sum of log amplitudes over a fractional-octave window: order sensitive, so it stays a host loop.
+void irb_averaging_filter(float *buffer, int fft_size, double octave_fraction, double sample_rate, int log_avg,
+                          int include_phase, int include_amplitude)
+{
+    if (!buffer || !is_pow2(fft_size)) return;                      // :412-415 (DBG + return)
+    std::vector<float> oldAmpl((size_t) fft_size / 2, 0.0f), newAmpl((size_t) fft_size, 0.0f);
+    const int N = fft_size / 2;
+    const double fractPerSide = octave_fraction / 2.0;
+    const double freqPerBin = (sample_rate / 2) / (double) (N / 2);
+    for (int bin = 0; bin <= N; bin += 2)
+        oldAmpl[bin / 2] = (float) std::sqrt(std::pow((double) buffer[bin], 2.0) + std::pow((double) buffer[bin + 1], 2.0));
+    float runningSum = 0.0f;
+    int prevLowerBin = 0, prevUpperBin = -2;
+    for (int bin = 0; bin <= N; bin += 2) {
+        const double binFreq = (bin / 2) * freqPerBin;
+        const int lowerBin = 2 * (int) std::round((binFreq / std::pow(2.0, fractPerSide)) / freqPerBin);
+        const int upperBin = 2 * (int) std::round((binFreq * std::pow(2.0, fractPerSide)) / freqPerBin);
+        const double binRangeLength = (double) (upperBin - lowerBin) / 2.0 + 1.0;
+        if (log_avg) {
+            for (int sb = prevLowerBin; sb < lowerBin; sb += 2) {
+                float v = oldAmpl[sb / 2];
+                round_to_1e16(&v);
+                runningSum -= std::log(v);
+            }
+            for (int ab = prevUpperBin + 2; ab <= upperBin; ab += 2) {
+                if (ab < fft_size) {
+                    float v = oldAmpl[ab / 2];
+                    round_to_1e16(&v);
+                    runningSum += std::log(v);
+                }
+            }
+        } else {
+            runningSum = 0.0f;
+            for (int i = lowerBin; i <= upperBin && i / 2 < fft_size / 2; i += 2) runningSum += oldAmpl[i / 2];
+        }
+        float na = (float) (runningSum / binRangeLength);
+        if (log_avg) na = std::exp(na);
+        round_to_1e16(&na);
+        newAmpl[bin] = na;
+        prevLowerBin = lowerBin;
+        prevUpperBin = upperBin;
+    }
+    for (int bin = 0; bin <= N; bin += 2) {
+        float ampl = newAmpl[bin];
+        round_to_zero(buffer + bin, 1e-11f);
+        round_to_zero(buffer + bin + 1, 1e-11f);
+        float phase = std::atan2(buffer[bin + 1], buffer[bin]);
+        if (!include_amplitude) ampl = 1.0f;
+        if (!include_phase) phase = 0.0f;
+        buffer[bin] = ampl * std::cos(phase);
+        buffer[bin + 1] = ampl * std::sin(phase);
+    }
+}
+
+void irb_shifteroo(float *buf, int n)                               // fp/ir.cpp:85-103
+{
+    if (!buf || n < 2) return;
+    const int second = n / 2, first = second + (n % 2 != 0 ? 1 : 0);
+    std::vector<float> t((size_t) n);
+    std::memcpy(t.data(), buf + first, sizeof(float) * (size_t) second);
+    std::memcpy(t.data() + second, buf, sizeof(float) * (size_t) first);
+    std::memcpy(buf, t.data(), sizeof(float) * (size_t) n);
+}
+
+// ---- convolution::deconvolve (fp/convolution.cpp:351-403) ---------------------------------------------
+int irb_deconvolve(int device, const float *num, int len_num, const float *den, int len_den, double sample_rate,
+                   int smoothing, int include_phase, int include_amplitude, float *out, int out_len)
+{
+    if (!num || !den || !out || len_num < 1 || len_den < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    const int len = std::max(len_num, len_den);                     // :359-362 the shorter one is zero extended
+    const int N = irb_next_power_of_two(len);                       // fp/tools.cpp:323
+    if (N < 32) return irb_set_error_(IRB_ERR_ARG, "buffers shorter than 17 samples are not supported");
+    if (out_len < N) return irb_set_error_(IRB_ERR_ARG, "out must hold nextPowerOfTwo(max(len)) samples");
+    irb_lfft *p = nullptr;
+    int rc = irb_lfft_create(device, N, 2, &p);
+    if (rc != IRB_OK) return rc;
+    do {
+        hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * 2 * (size_t) N, p->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_time, num, sizeof(float) * len_num, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_time + N, den, sizeof(float) * len_den, hipMemcpyHostToDevice, p->stream);
+        if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "upload", hipGetErrorString(e)); break; }
+        rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, 2);   // :365-366 both transforms in one batch
+        if (rc != IRB_OK) break;
+        const int nbins = N / 2 + 1;                                // :373-378 bins 0..N/2
+        irb::k_cdiv<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
+            reinterpret_cast<float2 *>(p->d_spec), reinterpret_cast<const float2 *>(p->d_spec + 2 * (size_t) N), nbins);
+        if ((e = hipGetLastError()) != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "k_cdiv", hipGetErrorString(e)); break; }
+        if (smoothing) {                                            // :389-394: host (order-sensitive running sums)
+            std::vector<float> spec(2 * (size_t) N, 0.0f);
+            e = hipMemcpyAsync(spec.data(), p->d_spec, sizeof(float) * (N + 2), hipMemcpyDeviceToHost, p->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "spectrum download", hipGetErrorString(e)); break; }
+            const float smoothPerAvg = 1.0 / 13.0;
+            for (int i = 0; i < 3; i++)
+                irb_averaging_filter(spec.data(), 2 * N, smoothPerAvg, sample_rate, 1, include_phase, include_amplitude);
+            e = hipMemcpyAsync(p->d_spec, spec.data(), sizeof(float) * (N + 2), hipMemcpyHostToDevice, p->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);       // spec goes out of scope
+            if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "spectrum upload", hipGetErrorString(e)); break; }
+        }
+        rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, 1);   // :397
+        if (rc != IRB_OK) break;
+        e = hipMemcpyAsync(out, p->d_time, sizeof(float) * N, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
+        if (!include_phase) irb_shifteroo(out, N);                  // :400
+    } while (0);
+    irb_lfft_destroy(p);
+    return rc;
+}
+
+// ---- ir::invertFilter (fp/ir.cpp:13-18): deconvolve(generatePulse(n), ir) with the default flags -------
+int irb_invert_filter(int device, const float *ir, int len, int sample_rate, float *out, int out_len)
+{
+    if (!ir || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    std::vector<float> pulse((size_t) len, 0.0f);
+    pulse[0] = 1.0f;                                                // tools::generatePulse(n, 0), fp/tools.cpp:235-241
+    return irb_deconvolve(device, pulse.data(), len, ir, len, (double) sample_rate, 1, 1, 1, out, out_len);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// lfft_kernels.hpp -- large real FFT for the config-5 deconvolution chain (gfx950).
+//
+// tools::fftTransform / fftInvTransform (reference fp/tools.cpp:321-369) transform ONE long buffer
+// (2^16 in the plug-in, 2^20 in BASELINE config 5).  An N-point real transform is an M = N/2 point
+// complex transform plus a split pass; for M > 2048 the complex transform is the classic four-step
+// factorisation M = M1*M2 built from the one-wave LDS transform of fft_wave.hpp:
+//   k_lfft_cols<M1>   one wave per column n2: gather z[n1*M2+n2], M1-point FFT, multiply by W_M^{n2*k1},
+//                     store T[k1*M2+n2]
+//   k_lfft_rows<M2>   one wave per row k1: M2-point FFT of T[k1*M2 + .], store Z[k1 + M1*k2]
+// Twiddles: per-size half tables for the wave FFT; W_N^e for the inter-pass factor and the real split
+// comes from two small tables, W_N^e = A[e / E] * B[e % E] (both computed in double on the host).
+// Spectrum layout at the interface is the reference's: 2N floats, interleaved (re, im) for bins 0..N/2
+// (Nyquist at float index N), the rest zero.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_wave.hpp"
+
+namespace irb {
+
+struct LfftArgs {
+    const float2 *tw1, *tw2;      // half tables for the M1- and M2-point wave FFTs (M1, M2 entries)
+    const float2 *tabA, *tabB;    // W_N^(i*E), i < N/E ; W_N^i, i < E
+    int           logE;           // E = 1 << logE
+    int           N, M, M1, M2, batch;
+};
+
+__device__ __forceinline__ float2 big_twiddle(const LfftArgs &a, unsigned e)    // W_N^e, e < N
+{
+    return cmul(a.tabA[e >> a.logE], a.tabB[e & ((1u << a.logE) - 1u)]);
+}
+
+template <int M1> struct WaveGeom { static constexpr int NF = M1 <= 1024 ? 4 : 2; };
+
+// ---- pass 1: columns ------------------------------------------------------------------------------
+template <int M1, bool INV>
+__global__ __launch_bounds__(kWave * WaveGeom<M1>::NF) void k_lfft_cols(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
+{
+    constexpr int NF = WaveGeom<M1>::NF;
+    __shared__ float2 l_tw[M1];
+    __shared__ float2 l_buf[NF][M1];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const long item = (long) blockIdx.x * NF + wave;
+    const bool live = item < (long) a.batch * a.M2;
+    const int n2 = (int) (item % a.M2);
+    const long b = item / a.M2;
+    for (int i = threadIdx.x; i < M1; i += blockDim.x) l_tw[i] = a.tw1[i];
+    if (live) {
+        const float2 *src = in + b * a.M + n2;
+        for (int n1 = lane; n1 < M1; n1 += kWave) l_buf[wave][n1] = src[(size_t) n1 * a.M2];
+    }
+    __syncthreads();
+    if (!live) return;
+    wave_fft<M1, INV>(l_buf[wave], l_tw, lane);
+    float2 *dst = out + b * a.M + n2;
+    for (int k1 = lane; k1 < M1; k1 += kWave) {
+        const float2 w = big_twiddle(a, 2u * (unsigned) n2 * (unsigned) k1);     // W_M^(n2*k1) = W_N^(2*n2*k1)
+        const float2 v = l_buf[wave][k1];
+        dst[(size_t) k1 * a.M2] = INV ? cmulc(v, w) : cmul(v, w);
+    }
+}
+
+// ---- pass 2: rows ---------------------------------------------------------------------------------
+template <int M2, bool INV>
+__global__ __launch_bounds__(kWave * WaveGeom<M2>::NF) void k_lfft_rows(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
+{
+    constexpr int NF = WaveGeom<M2>::NF;
+    __shared__ float2 l_tw[M2];
+    __shared__ float2 l_buf[NF][M2];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const long item = (long) blockIdx.x * NF + wave;
+    const bool live = item < (long) a.batch * a.M1;
+    const int k1 = (int) (item % a.M1);
+    const long b = item / a.M1;
+    for (int i = threadIdx.x; i < M2; i += blockDim.x) l_tw[i] = a.tw2[i];
+    if (live) {
+        const float2 *src = in + b * a.M + (size_t) k1 * M2;
+        for (int n2 = lane; n2 < M2; n2 += kWave) l_buf[wave][n2] = src[n2];
+    }
+    __syncthreads();
+    if (!live) return;
+    wave_fft<M2, INV>(l_buf[wave], l_tw, lane);
+    float2 *dst = out + b * a.M + k1;
+    for (int k2 = lane; k2 < M2; k2 += kWave) dst[(size_t) k2 * a.M1] = l_buf[wave][k2];
+}
+
+// ---- M <= 2048: the whole complex transform in one wave ----------------------------------------------
+template <int M, bool INV>
+__global__ __launch_bounds__(kWave * WaveGeom<M>::NF) void k_lfft_small(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
+{
+    constexpr int NF = WaveGeom<M>::NF;
+    __shared__ float2 l_tw[M];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const long b = (long) blockIdx.x * NF + wave;
+    const bool live = b < a.batch;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) l_tw[i] = a.tw1[i];
+    if (live)
+        for (int n = lane; n < M; n += kWave) l_buf[wave][n] = in[b * M + n];
+    __syncthreads();
+    if (!live) return;
+    wave_fft<M, INV>(l_buf[wave], l_tw, lane);
+    for (int n = lane; n < M; n += kWave) out[b * M + n] = l_buf[wave][n];
+}
+
+// ---- real <-> complex split passes (element-wise over bin pairs b, M-b) ---------------------------------
+// forward: Z = FFT_M(z) -> spec: 2N floats per batch item, bins 0..M interleaved, zeros above
+// (performRealOnlyForwardTransform's layout; unnormalised)
+__global__ __launch_bounds__(256) void k_rsplit_fwd(LfftArgs a, const float2 *__restrict__ Z, float *__restrict__ spec)
+{
+    const int M = a.M;
+    const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = M / 2 + 1;
+    if (idx >= per * a.batch) return;
+    const int b = (int) (idx % per);
+    const long bt = idx / per;
+    const float2 *z = Z + bt * M;
+    float2 *X = reinterpret_cast<float2 *>(spec + bt * 2 * a.N);
+    if (b == 0) {
+        X[0] = make_float2(z[0].x + z[0].y, 0.0f);
+        X[M] = make_float2(z[0].x - z[0].y, 0.0f);
+    } else {
+        const float2 p = z[b], q = z[M - b];
+        const float2 e = make_float2(0.5f * (p.x + q.x), 0.5f * (p.y - q.y));
+        const float2 o = make_float2(0.5f * (p.y + q.y), -0.5f * (p.x - q.x));
+        const float2 t = cmul(big_twiddle(a, (unsigned) b), o);
+        X[b] = cadd(e, t);
+        if (b != M - b) X[M - b] = make_float2(e.x - t.x, t.y - e.y);
+    }
+    // clear the unused upper half (float indices N+2 .. 2N): bins M+1 .. N-1
+    for (long i = idx + M + 1 - bt * per; i < a.N; i += per) X[i] = make_float2(0.f, 0.f);
+}
+
+// inverse: spec (bins 0..M) -> Z with IFFT_M(Z)[n] = N*(y[2n] + i*y[2n+1])
+__global__ __launch_bounds__(256) void k_rsplit_inv(LfftArgs a, const float *__restrict__ spec, float2 *__restrict__ Z)
+{
+    const int M = a.M;
+    const long idx = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = M / 2 + 1;
+    if (idx >= per * a.batch) return;
+    const int b = (int) (idx % per);
+    const long bt = idx / per;
+    const float2 *X = reinterpret_cast<const float2 *>(spec + bt * 2 * a.N);
+    float2 *z = Z + bt * M;
+    if (b == 0) {
+        // performRealOnlyInverseTransform rebuilds the negative half from bins 0..N/2 and takes the real
+        // part of the result: only Re of DC and Nyquist survive
+        z[0] = make_float2(X[0].x + X[M].x, X[0].x - X[M].x);
+    } else {
+        const float2 p = X[b], q = X[M - b];
+        const float2 e = make_float2(p.x + q.x, p.y - q.y);
+        const float2 d = make_float2(p.x - q.x, p.y + q.y);
+        const float2 o = cmulc(d, big_twiddle(a, (unsigned) b));
+        z[b] = make_float2(e.x - o.y, e.y + o.x);
+        if (b != M - b) z[M - b] = make_float2(e.x + o.y, o.x - e.y);
+    }
+}
+
+// z (M complex per item, = N reals interleaved) * 1/N -> N real samples
+__global__ __launch_bounds__(256) void k_scale_real(const float *__restrict__ z, float *__restrict__ y, long n, float scale)
+{
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = z[i] * scale;
+}
+
+// tools::complexDivCartesian over bins 0..N/2 (reference fp/convolution.cpp:373-378, fp/tools.cpp:72-86):
+// num /= den in place, a zero denominator leaves the numerator as it is
+__global__ __launch_bounds__(256) void k_cdiv(float2 *__restrict__ num, const float2 *__restrict__ den, int nbins)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    const float a = num[i].x, b = num[i].y, c = den[i].x, d = den[i].y;
+    if (c == 0.0f && d == 0.0f) return;
+    const float den2 = c * c + d * d;
+    num[i] = make_float2((a * c + b * d) / den2, (b * c - a * d) / den2);
+}
+
+}  // namespace irb

@@ -44,3 +44,25 @@ def delta_ir(n=2048, offset=100):
         offset = 0
     h[offset] = 1.0
     return h
+
+
+def exp_sine_sweep(n_sweep, sample_rate, f_lo=20.0, f_hi=None, fade_from=None, n_total=None):
+    """Farina exponential sine sweep as the plug-in builds it (input generator only):
+    sweep[i] = sin(K*(exp(i/L)-1)), K = T*w1/ln(w2/w1), L = T/ln(w2/w1)
+    (fp/ExpSineSweep.cpp:26-41,212-220), linear fade-out from frequency `fade_from`
+    (:147-164, Source/PluginProcessor.cpp:29-30), followed by silence up to n_total samples."""
+    f_hi = sample_rate / 2.0 if f_hi is None else f_hi
+    T = float(n_sweep)
+    w1, w2 = f_lo / sample_rate * 2 * np.pi, f_hi / sample_rate * 2 * np.pi
+    K, L = T * w1 / np.log(w2 / w1), T / np.log(w2 / w1)
+    i = np.arange(n_sweep, dtype=np.float64)
+    s = np.sin(K * (np.exp(i / L) - 1.0))
+    if fade_from is not None:
+        wf = fade_from / sample_rate * 2 * np.pi
+        idx = int(L * np.log(wf / w1))                     # sample index where the sweep reaches fade_from
+        idx = min(max(idx, 0), n_sweep - 1)
+        n = n_sweep - idx
+        s[idx:] *= (n - np.arange(n)) / n
+    out = np.zeros(n_total if n_total else n_sweep, np.float32)
+    out[:n_sweep] = s.astype(np.float32)
+    return out

@@ -328,6 +328,186 @@ int fp_convolveNonPeriodic(const float *const *audio, int audio_ch, int La,
 }
 
 /* ------------------------------------------------------------------------- */
+/* config-5 chain                                                              */
+/* ------------------------------------------------------------------------- */
+
+/* fp/tools.cpp:180-196 */
+int fp_nextPowerOfTwo(int x)
+{
+    if (x != 0 && (x & (x - 1)) == 0) return x;
+    int r = 1;
+    while (r <= x) r *= 2;      /* recursion at :189-196: first power of two strictly above x */
+    return r;
+}
+
+/* fp/tools.cpp:321-346 (formatAmplPhase = false) */
+int fp_fftTransform(const float *in, int len, float *out)
+{
+    const int N = fp_nextPowerOfTwo(len);
+    memset(out, 0, sizeof(float) * 2 * (size_t) N);
+    memcpy(out, in, sizeof(float) * (size_t) len);
+    fp_fft *f = fp_fft_create(highest_bit(N));
+    fp_fft_forward_real(f, out);
+    fp_fft_destroy(f);
+    return N;
+}
+
+/* fp/tools.cpp:351-369 */
+void fp_fftInvTransform(const float *in, int fftSize, float *out)
+{
+    const int N = fftSize / 2;
+    float *tmp = (float *) malloc(sizeof(float) * (size_t) fftSize);
+    memcpy(tmp, in, sizeof(float) * (size_t) fftSize);
+    fp_fft *f = fp_fft_create(highest_bit(N));
+    fp_fft_inverse_real(f, tmp);
+    fp_fft_destroy(f);
+    memcpy(out, tmp, sizeof(float) * (size_t) N);      /* :366 result is in the first half */
+    free(tmp);
+}
+
+/* fp/tools.cpp:72-86 */
+void fp_complexDivCartesian(float *a, float *b, float c, float d)
+{
+    if (c == 0.0 && d == 0.0) return;
+    float re = ((*a) * c + (*b) * d) / (c * c + d * d);
+    float im = ((*b) * c - (*a) * d) / (c * c + d * d);
+    *a = re;
+    *b = im;
+}
+
+/* fp/tools.cpp:199-209 */
+static void roundToZero(float *x, float threshold)
+{
+    if (threshold < 0.0f) return;
+    if (!signbit(*x) && *x < threshold) *x = 0.0f;
+    if (signbit(*x) && *x > -(threshold)) *x = 0.0f;
+}
+
+/* fp/tools.cpp:213-218 */
+static void roundTo1TenQuadrillionth(float *x)
+{
+    if (!signbit(*x) && *x < 1e-16) *x = 1e-16;
+    if (signbit(*x) && *x > -1e-16) *x = -1e-16;
+}
+
+/* fp/tools.cpp:222-231; float arguments pick the float overloads of atan2 in C++ */
+static float binAmpl(const float *p) { return (float) sqrt(pow((double) p[0], 2.0) + pow((double) p[1], 2.0)); }
+static float binPhase(const float *p) { return atan2f(p[1], p[0]); }
+
+/* fp/convolution.cpp:406-546, one channel */
+void fp_averagingFilter(float *buffer, int fftSize, double octaveFraction, double sampleRate, int logAvg,
+                        int includePhase, int includeAmplitude)
+{
+    if (!(fftSize != 0 && (fftSize & (fftSize - 1)) == 0)) return;           /* :412-415 */
+    float *oldAmpl = (float *) calloc((size_t) fftSize / 2, sizeof(float));   /* :417 real-frequency amplitudes */
+    float *newAmpl = (float *) calloc((size_t) fftSize, sizeof(float));       /* :418 */
+    const int N = fftSize / 2;
+    const double fractPerSide = octaveFraction / 2.0;
+    const double nyquist = sampleRate / 2;
+    const double freqPerBin = nyquist / (double) (N / 2);                     /* :425 */
+
+    for (int bin = 0; bin <= N; bin += 2) oldAmpl[bin / 2] = binAmpl(buffer + bin);   /* :429-436 */
+
+    float runningSum = 0.0f;
+    int prevLowerBin = 0, prevUpperBin = -2;
+    for (int bin = 0; bin <= N; bin += 2) {                                   /* :449 */
+        double binFreq = (bin / 2) * freqPerBin;
+        double lowerFreq = binFreq / pow(2.0, fractPerSide);
+        int lowerBin = 2 * (int) round(lowerFreq / freqPerBin);
+        double upperFreq = binFreq * pow(2.0, fractPerSide);
+        int upperBin = 2 * (int) round(upperFreq / freqPerBin);
+        double binRangeLength = (double) (upperBin - lowerBin) / 2.0 + 1.0;
+        if (logAvg) {                                                         /* :482-505 */
+            int subtractBin = prevLowerBin;
+            while (subtractBin < lowerBin) {
+                float v = oldAmpl[subtractBin / 2];
+                roundTo1TenQuadrillionth(&v);
+                v = logf(v);
+                runningSum -= v;
+                subtractBin += 2;
+            }
+            int addBin = prevUpperBin + 2;
+            while (addBin <= upperBin) {
+                if (addBin < fftSize) {
+                    float v = oldAmpl[addBin / 2];
+                    roundTo1TenQuadrillionth(&v);
+                    v = logf(v);
+                    runningSum += v;
+                }
+                addBin += 2;
+            }
+        } else {                                                              /* :509-515 */
+            runningSum = 0.0f;
+            for (int i = lowerBin; i <= upperBin; i += 2) runningSum += oldAmpl[i / 2];
+        }
+        float na = (float) (runningSum / binRangeLength);                     /* :519 */
+        if (logAvg) na = expf(na);
+        roundTo1TenQuadrillionth(&na);
+        newAmpl[bin] = na;
+        prevLowerBin = lowerBin;
+        prevUpperBin = upperBin;
+    }
+    for (int bin = 0; bin <= N; bin += 2) {                                   /* :531-543 */
+        float ampl = newAmpl[bin];
+        roundToZero(buffer + bin, 1e-11f);
+        roundToZero(buffer + bin + 1, 1e-11f);
+        float phase = binPhase(buffer + bin);
+        if (!includeAmplitude) ampl = 1.0f;
+        if (!includePhase) phase = 0.0f;
+        buffer[bin] = ampl * cosf(phase);
+        buffer[bin + 1] = ampl * sinf(phase);
+    }
+    free(oldAmpl); free(newAmpl);
+}
+
+/* fp/ir.cpp:85-103 */
+void fp_shifteroo(float *buf, int n)
+{
+    if (n < 2) return;
+    int second = n / 2, first = second + (n % 2 != 0 ? 1 : 0);
+    float *t = (float *) malloc(sizeof(float) * (size_t) n);
+    memcpy(t, buf + first, sizeof(float) * (size_t) second);
+    memcpy(t + second, buf, sizeof(float) * (size_t) first);
+    memcpy(buf, t, sizeof(float) * (size_t) n);
+    free(t);
+}
+
+/* fp/convolution.cpp:351-403.  setSize(.., keepExisting) = zero extension. */
+int fp_deconvolve(const float *num, int len_num, const float *den, int len_den, double sampleRate,
+                  int smoothing, int includePhase, int includeAmplitude, float *out)
+{
+    const int len = len_num > len_den ? len_num : len_den;                    /* :359-362 */
+    const int N = fp_nextPowerOfTwo(len);
+    float *a = (float *) calloc((size_t) len, sizeof(float)), *b = (float *) calloc((size_t) len, sizeof(float));
+    memcpy(a, num, sizeof(float) * (size_t) len_num);
+    memcpy(b, den, sizeof(float) * (size_t) len_den);
+    float *A = (float *) malloc(sizeof(float) * 2 * (size_t) N), *Bf = (float *) malloc(sizeof(float) * 2 * (size_t) N);
+    fp_fftTransform(a, len, A);                                               /* :365-366 */
+    fp_fftTransform(b, len, Bf);
+    for (int i = 0; i <= N; i += 2)                                           /* :373-378 */
+        fp_complexDivCartesian(A + i, A + i + 1, Bf[i], Bf[i + 1]);
+    if (smoothing) {                                                          /* :389-394 */
+        float smoothPerAvg = 1.0 / 13.0;
+        for (int i = 0; i < 3; i++)
+            fp_averagingFilter(A, 2 * N, smoothPerAvg, sampleRate, 1, includePhase, includeAmplitude);
+    }
+    fp_fftInvTransform(A, 2 * N, out);                                        /* :397 */
+    if (!includePhase) fp_shifteroo(out, N);                                  /* :400 */
+    free(a); free(b); free(A); free(Bf);
+    return N;
+}
+
+/* fp/ir.cpp:13-18 with tools::generatePulse(n) = delta at 0 (fp/tools.cpp:235-241, tools.hpp default) */
+int fp_invertFilter(const float *ir, int len, int sampleRate, float *out)
+{
+    float *pulse = (float *) calloc((size_t) len, sizeof(float));
+    pulse[0] = 1.0f;
+    int N = fp_deconvolve(pulse, len, ir, len, (double) sampleRate, 1, 1, 1, out);
+    free(pulse);
+    return N;
+}
+
+/* ------------------------------------------------------------------------- */
 /* fp::CircularBufferArray (fp/CircularBufferArray.cpp:94-128, 193-205)       */
 /* ------------------------------------------------------------------------- */
 

@@ -57,6 +57,25 @@ int fp_convolveNonPeriodic(const float *const *audio, int audio_ch, int La,
                            const float *const *ir, int ir_ch, int Lh,
                            float *const *out);
 
+/* ---- config-5 chain: tools::fftTransform / fftInvTransform (fp/tools.cpp:321-369),
+ *      tools::complexDivCartesian (:72-86), convolution::averagingFilter (fp/convolution.cpp:406-546),
+ *      convolution::deconvolve (:351-403), ir::shifteroo (fp/ir.cpp:85-103), ir::invertFilter (:13-18),
+ *      tools::generatePulse (fp/tools.cpp:235-241).  Mono buffers, as deconvolve forces (:353-356). ---- */
+int  fp_nextPowerOfTwo(int x);
+/* in: len samples; out: 2*N floats, N = nextPowerOfTwo(len); returns N */
+int  fp_fftTransform(const float *in, int len, float *out);
+/* in: 2*N floats (fftSize = 2N); out: N samples */
+void fp_fftInvTransform(const float *in, int fftSize, float *out);
+void fp_complexDivCartesian(float *a, float *b, float c, float d);
+/* buffer: fftSize floats (one channel), modified in place */
+void fp_averagingFilter(float *buffer, int fftSize, double octaveFraction, double sampleRate, int logAvg,
+                        int includePhase, int includeAmplitude);
+/* out: N = nextPowerOfTwo(max(len_num, len_den)) samples; returns N */
+int  fp_deconvolve(const float *num, int len_num, const float *den, int len_den, double sampleRate,
+                   int smoothing, int includePhase, int includeAmplitude, float *out);
+void fp_shifteroo(float *buf, int n);
+int  fp_invertFilter(const float *ir, int len, int sampleRate, float *out);
+
 /* ---- IRBaboonAudioProcessor convolution state (Source/PluginProcessor.cpp
  *      ctor :57-82, prepareToPlay :164-234, processBlock IDLE branch :408-562,
  *      rings per fp/CircularBufferArray.cpp:94-128) ----

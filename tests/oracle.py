@@ -137,3 +137,75 @@ class RtProcessor:
             lib().fp_rt_destroy(self.p)
         except Exception:
             pass
+
+
+# ---- config-5 chain (fp/convolution.cpp:351-546, fp/tools.cpp:321-369, fp/ir.cpp:13-18,85-103) ----
+def _bind_cfg5():
+    l = lib()
+    if getattr(l, "_cfg5_bound", False):
+        return l
+    fp = C.POINTER(C.c_float)
+    l.fp_nextPowerOfTwo.restype = C.c_int
+    l.fp_nextPowerOfTwo.argtypes = [C.c_int]
+    l.fp_fftTransform.restype = C.c_int
+    l.fp_fftTransform.argtypes = [fp, C.c_int, fp]
+    l.fp_fftInvTransform.argtypes = [fp, C.c_int, fp]
+    l.fp_averagingFilter.argtypes = [fp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    l.fp_deconvolve.restype = C.c_int
+    l.fp_deconvolve.argtypes = [fp, C.c_int, fp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, fp]
+    l.fp_shifteroo.argtypes = [fp, C.c_int]
+    l.fp_invertFilter.restype = C.c_int
+    l.fp_invertFilter.argtypes = [fp, C.c_int, C.c_int, fp]
+    l._cfg5_bound = True
+    return l
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def next_pow2(x):
+    return _bind_cfg5().fp_nextPowerOfTwo(int(x))
+
+
+def fft_transform(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(2 * next_pow2(x.size), np.float32)
+    _bind_cfg5().fp_fftTransform(_f(x), x.size, _f(out))
+    return out
+
+
+def fft_inv_transform(buf):
+    buf = np.ascontiguousarray(buf, np.float32)
+    out = np.zeros(buf.size // 2, np.float32)
+    _bind_cfg5().fp_fftInvTransform(_f(buf), buf.size, _f(out))
+    return out
+
+
+def averaging_filter(buf, octave_fraction, sample_rate, log_avg=True, include_phase=True, include_amplitude=True):
+    buf = np.ascontiguousarray(buf, np.float32).copy()
+    _bind_cfg5().fp_averagingFilter(_f(buf), buf.size, octave_fraction, sample_rate, int(log_avg),
+                                    int(include_phase), int(include_amplitude))
+    return buf
+
+
+def deconvolve(num, den, sample_rate, smoothing=True, include_phase=True, include_amplitude=True):
+    num = np.ascontiguousarray(num, np.float32)
+    den = np.ascontiguousarray(den, np.float32)
+    out = np.zeros(next_pow2(max(num.size, den.size)), np.float32)
+    _bind_cfg5().fp_deconvolve(_f(num), num.size, _f(den), den.size, float(sample_rate), int(smoothing),
+                               int(include_phase), int(include_amplitude), _f(out))
+    return out
+
+
+def shifteroo(x):
+    x = np.ascontiguousarray(x, np.float32).copy()
+    _bind_cfg5().fp_shifteroo(_f(x), x.size)
+    return x
+
+
+def invert_filter(ir, sample_rate):
+    ir = np.ascontiguousarray(ir, np.float32)
+    out = np.zeros(next_pow2(ir.size), np.float32)
+    _bind_cfg5().fp_invertFilter(_f(ir), ir.size, int(sample_rate), _f(out))
+    return out

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "irb_fdl.h")).read()
+    src = open(os.path.join(ROOT, "include", "irb_fdl.h")).read() + open(os.path.join(ROOT, "include", "irb_deconv.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(irb_[a-z_0-9]+)\s*\(", src)))
 

@@ -1,0 +1,117 @@
+"""GPU parity of the config-5 chain (large real FFT, spectral division, deconvolve, invertFilter) against
+the oracle, through the C ABI.  The oracle for this chain is parity unpinned (no reference fixtures exist);
+its own pins are in tests/test_oracle_cfg5.py."""
+import numpy as np
+import pytest
+
+import oracle
+import irbaboon_amd as ib
+from irbaboon_amd.synth import decaying_ir, exp_sine_sweep, white_noise
+from util import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _bins(F, N):
+    return F[0:N + 2:2].astype(np.float64) + 1j * F[1:N + 2:2].astype(np.float64)
+
+
+@pytest.mark.parametrize("n", [17, 100, 1000, 4096, 5000, 1 << 13, 1 << 16, (1 << 16) + 1, 1 << 20])
+def test_fft_transform_matches_oracle_and_numpy(n):
+    x = white_noise(n, n)
+    F = ib.fftTransform(x)
+    N = ib.nextPowerOfTwo(n)
+    assert F.size == 2 * N and N == oracle.next_pow2(n)
+    ref = np.fft.rfft(np.pad(x.astype(np.float64), (0, N - n)))
+    got = _bins(F, N)
+    assert np.sqrt(np.mean(np.abs(got - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 2e-6
+    assert rel_rms(np.abs(got), np.abs(_bins(oracle.fft_transform(x), N))) < 1e-5
+    assert not F[N + 2:].any()                                  # unused upper half is cleared
+    y = ib.fftInvTransform(F)
+    assert y.size == N and rel_rms(y[:n], x) < 1e-5 and (n == N or np.abs(y[n:]).max() < 1e-5)
+
+
+def test_fft_transform_rejects_tiny_buffers():
+    with pytest.raises(ib.IrbError):
+        ib.fftTransform(np.ones(8, np.float32))
+
+
+def test_host_helpers_match_oracle_exactly():
+    N = 4096
+    F = oracle.fft_transform(decaying_ir(9, N))
+    for kw in ({}, {"includePhase": False}, {"includeAmplitude": False}, {"logAvg": False}):
+        a = F.copy()
+        ib.averagingFilter(a, 1.0 / 13.0, 48000.0, **kw)
+        b = oracle.averaging_filter(F, 1.0 / 13.0, 48000.0, log_avg=kw.get("logAvg", True),
+                                    include_phase=kw.get("includePhase", True), include_amplitude=kw.get("includeAmplitude", True))
+        assert np.array_equal(a, b)                              # same libm, same operation order
+    for n in (5, 6, 2, 1):
+        v = np.arange(n, dtype=np.float32)
+        w = v.copy()
+        ib.shifteroo(w)
+        assert np.array_equal(w, oracle.shifteroo(v))
+
+
+@pytest.mark.parametrize("smoothing,phase,ampl", [(False, True, True), (True, True, True), (True, False, True), (True, True, False)])
+def test_deconvolve_well_conditioned_matches_oracle(smoothing, phase, ampl):
+    den = decaying_ir(5, 6000)
+    den[0] += 4.0                                               # |D(f)| bounded away from zero
+    num = np.convolve(den.astype(np.float64), decaying_ir(6, 300).astype(np.float64))[:6000].astype(np.float32)
+    got = ib.deconvolve(num, den, 48000, smoothing, phase, ampl)
+    ref = oracle.deconvolve(num, den, 48000, smoothing, phase, ampl)
+    assert got.shape == ref.shape == (8192,)
+    assert rel_rms(got, ref) < 1e-5
+
+
+def test_deconvolve_plugin_geometry_sweep():
+    """The plug-in's own call (Source/PluginProcessor.cpp:306): 65536-sample capture / sweep, defaults."""
+    sr = 48000
+    sweep = exp_sine_sweep(49152, sr, 20.0, sr / 2, fade_from=(11.0 / 12.0) * sr / 2, n_total=65536)
+    h = decaying_ir(77, 512)
+    cap = np.convolve(sweep.astype(np.float64), h.astype(np.float64))[:65536].astype(np.float32)
+    for smoothing in (False, True):
+        got = ib.deconvolve(cap, sweep, sr, smoothing)
+        ref = oracle.deconvolve(cap, sweep, sr, smoothing)
+        # the sweep has almost no energy below 20 Hz: those bins divide rounding noise by ~0 and differ
+        # between any two FFT implementations, so compare where the division is conditioned (40 Hz..20 kHz)
+        G, R = np.fft.rfft(got.astype(np.float64)), np.fft.rfft(ref.astype(np.float64))
+        band = slice(int(40 / sr * 65536), int(20000 / sr * 65536))
+        assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
+
+
+def test_deconvolve_zero_denominator_bins_are_skipped():
+    # den = delta - delayed delta has exact spectral zeros; fp/tools.cpp:74-77 leaves those bins alone
+    N = 1024
+    den = np.zeros(N, np.float32)
+    den[0] = 1.0
+    num = white_noise(3, N)
+    assert rel_rms(ib.deconvolve(num, den, 48000, smoothing=False), num) < 1e-5      # division by 1
+    z = np.zeros(N, np.float32)
+    got = ib.deconvolve(num, z, 48000, smoothing=False)
+    assert rel_rms(got, num) < 1e-5                                                  # every denominator 0: untouched
+    assert rel_rms(got, oracle.deconvolve(num, z, 48000, smoothing=False)) < 1e-5
+
+
+def test_invert_filter_matches_oracle():
+    h = decaying_ir(3, 2048)
+    h[0] += 2.0
+    got, ref = ib.invertFilter(h, 48000), oracle.invert_filter(h, 48000)
+    assert rel_rms(got, ref) < 1e-5
+    c = np.fft.irfft(np.fft.rfft(h.astype(np.float64)) * np.fft.rfft(got.astype(np.float64)))
+    assert abs(c[0]) > 0.8
+
+
+def test_config5_full_size_one_million_samples():
+    """BASELINE configs[4]: 2^20-sample sweep capture -> IR extraction; smoothing off so the answer is known."""
+    sr, N = 48000, 1 << 20
+    sweep = exp_sine_sweep(3 * N // 4, sr, 20.0, sr / 2, fade_from=(11.0 / 12.0) * sr / 2, n_total=N)
+    h = decaying_ir(55, 4096)
+    cap = np.fft.irfft(np.fft.rfft(sweep.astype(np.float64)) * np.fft.rfft(np.pad(h.astype(np.float64), (0, N - 4096)))).astype(np.float32)
+    got = ib.deconvolve(cap, sweep, sr, smoothing=False)
+    assert got.size == N
+    G, Href = np.fft.rfft(got.astype(np.float64)), np.fft.rfft(np.pad(h.astype(np.float64), (0, N - 4096)))
+    band = slice(int(40 / sr * N), int(20000 / sr * N))
+    assert np.sqrt(np.mean(np.abs(G[band] - Href[band]) ** 2) / np.mean(np.abs(Href[band]) ** 2)) < 1e-3
+    ref = oracle.deconvolve(cap, sweep, sr, smoothing=False)
+    R = np.fft.rfft(ref.astype(np.float64))
+    assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
