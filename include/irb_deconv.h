@@ -47,6 +47,19 @@ int  irb_deconvolve(int device, const float *num, int len_num, const float *den,
 /* Replaces: ir::invertFilter(buffer, sampleRate) (fp/ir.cpp:13-18). */
 int  irb_invert_filter(int device, const float *ir, int len, int sample_rate, float *out, int out_len);
 
+/* Replaces: AudioBuffer<float> convolution::convolveNonPeriodic(audio, ir) (fp/convolution.cpp:246-347): one
+ * FFT of length N = smallest power of two >= La+Lh-1 per signal, bin-wise product over bins 0..N/2
+ * (tools::complexMul), inverse, first La+Lh-1 samples.  Same channel-layout rules and error behaviour as
+ * irb_convolve_periodic (unknown layout: cleared output + IRB_ERR_LAYOUT).  out: [audio_ch][La+Lh-1]. */
+int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch, int La,
+                              const float *const *ir, int ir_ch, int Lh, float *const *out);
+
+/* Replaces: ir::IRtoRealFFTRaw(buffer, irPartSize) (fp/ir.cpp:106-147) without its hard-coded text dump:
+ * the mono IR cut into len/irPartSize + 1 partitions, each transformed with N = 2*irPartSize and packed
+ * (im(0) := re(N/2)), consolidated as rows of N floats.  irPartSize must be a power of two >= 16.
+ * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows. */
+int  irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);
+
 /* ---- reusable plan with device-resident buffers (bench, repeated transforms) ---- */
 int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
 void irb_lfft_destroy(irb_lfft *p);

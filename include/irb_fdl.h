@@ -93,6 +93,15 @@ int  irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_cha
  * audio channels there, :485).                                                   */
 int  irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const float *samples);
 
+/* IR partition spectra as an interchange format: n_partitions rows of N floats per IR channel, each row
+ * the partition's N-point real FFT with im(0) replaced by re(N/2) -- the packing the reference itself
+ * uses when it exports partitioned IR spectra (ir::IRtoRealFFTRaw, fp/ir.cpp:106-147, :123-124).  This is
+ * exactly the engine's HBM layout, so set/get are plain copies.  `get` reads the set that audio channel
+ * `channel` of `instance` multiplies with; `set` follows the channel-layout rules of irb_fdl_set_ir
+ * (a stereo IR for mono audio must be summed to mono by the caller before its transform). */
+int  irb_fdl_get_ir_spectra(irb_fdl *h, int instance, int channel, float *spectra, int n_partitions);
+int  irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra, int ir_channels, int n_partitions);
+
 /* Zero the FDL and the overlap (what a fresh convolvePeriodic call starts from,
  * fp/convolution.cpp:59,67,81,87).  IR spectra are kept.                         */
 int  irb_fdl_reset(irb_fdl *h);

@@ -42,6 +42,8 @@ SYMBOLS = [
     ("irb_fdl_get_info", C.c_int, [C.c_void_p, C.POINTER(FdlInfo)]),
     ("irb_fdl_set_ir", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
     ("irb_fdl_set_ir_partition", C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    ("irb_fdl_get_ir_spectra", C.c_int, [C.c_void_p, C.c_int, C.c_int, fp, C.c_int]),
+    ("irb_fdl_set_ir_spectra", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
     ("irb_fdl_reset", C.c_int, [C.c_void_p]),
     ("irb_fdl_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
     ("irb_fdl_process_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
@@ -68,6 +70,8 @@ SYMBOLS = [
     ("irb_shifteroo", None, [fp, C.c_int]),
     ("irb_deconvolve", C.c_int, [C.c_int, fp, C.c_int, fp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, fp, C.c_int]),
     ("irb_invert_filter", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int]),
+    ("irb_convolve_nonperiodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, fpp]),
+    ("irb_ir_to_real_fft_raw", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]),
     ("irb_lfft_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_lfft_destroy", None, [C.c_void_p]),
     ("irb_lfft_buffers", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -47,3 +47,30 @@ def convolvePeriodic(buffer1, buffer2, processBlockSize=256, device=0, keep_refe
         return out
     _lib.check(rc)
     return out
+
+
+def convolveNonPeriodic(buffer1, buffer2, device=0):
+    """fp::convolution::convolveNonPeriodic(buffer1 = audio, buffer2 = IR) (fp/convolution.cpp:246-347):
+    one large FFT per signal on the GPU.  Unknown layout: cleared buffer + debug line (:271-275)."""
+    a = np.ascontiguousarray(np.atleast_2d(buffer1), np.float32)
+    h = np.ascontiguousarray(np.atleast_2d(buffer2), np.float32)
+    out = np.zeros((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
+    rc = _lib.lib().irb_convolve_nonperiodic(device, planar_ptrs(a), a.shape[0], a.shape[1],
+                                             planar_ptrs(h), h.shape[0], h.shape[1], planar_ptrs(out))
+    if rc == _lib.IRB_ERR_LAYOUT:
+        print("Either buffer1 or buffer2 is not mono nor stereo. Abort abort", file=sys.stderr)
+        return out
+    _lib.check(rc)
+    return out
+
+
+def IRtoRealFFTRaw(buffer, irPartSize, device=0):
+    """fp::ir::IRtoRealFFTRaw (fp/ir.cpp:106-147): [len/irPartSize + 1][2*irPartSize] packed partition spectra."""
+    import ctypes as C
+    ir = np.ascontiguousarray(buffer, np.float32).reshape(-1)
+    rows = ir.size // irPartSize + 1
+    out = np.zeros((rows, 2 * irPartSize), np.float32)
+    n = C.c_int()
+    _lib.check(_lib.lib().irb_ir_to_real_fft_raw(device, ir.ctypes.data_as(_lib.fp), ir.size, irPartSize,
+                                                 out.ctypes.data_as(_lib.fp), out.size, C.byref(n)))
+    return out

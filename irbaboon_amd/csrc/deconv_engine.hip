@@ -411,4 +411,83 @@ int irb_invert_filter(int device, const float *ir, int len, int sample_rate, flo
     return irb_deconvolve(device, pulse.data(), len, ir, len, (double) sample_rate, 1, 1, 1, out, out_len);
 }
 
+// ---- convolution::convolveNonPeriodic (fp/convolution.cpp:246-347) ------------------------------------
+int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch, int La,
+                             const float *const *ir, int ir_ch, int Lh, float *const *out)
+{
+    if (!audio || !ir || !out || La < 0 || Lh < 0 || audio_ch < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    const long Lout = (long) La + Lh - 1;                             // :251
+    for (int c = 0; c < audio_ch; c++) {
+        if (!out[c]) return irb_set_error_(IRB_ERR_ARG, "null output channel");
+        if (Lout > 0) std::memset(out[c], 0, sizeof(float) * (size_t) Lout);
+    }
+    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2)))   // :262-275
+        return irb_set_error_(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
+    if (Lout <= 0 || La == 0 || Lh == 0) return IRB_OK;
+    if (Lout > (1 << 23)) return irb_set_error_(IRB_ERR_ARG, "result longer than 2^23 samples");
+    int N = 1;
+    while (N < Lout) N *= 2;                                          // :278-281
+    N = std::max(N, 32);                                              // longer zero padding: same linear convolution
+    const int ir_rows = (ir_ch == 2 && audio_ch == 2) ? 2 : 1;        // :296-304
+    const int batch = audio_ch + ir_rows;
+    irb_lfft *p = nullptr;
+    int rc = irb_lfft_create(device, N, batch, &p);
+    if (rc != IRB_OK) return rc;
+    do {
+        std::vector<float> host((size_t) batch * N, 0.0f);
+        for (int c = 0; c < audio_ch; c++) std::memcpy(&host[(size_t) c * N], audio[c], sizeof(float) * (size_t) La);
+        for (int r = 0; r < ir_rows; r++) std::memcpy(&host[(size_t) (audio_ch + r) * N], ir[r], sizeof(float) * (size_t) Lh);
+        if (ir_ch == 2 && audio_ch == 1) {                            // tools::sumToMono, fp/tools.cpp:25-28
+            float *p0 = &host[(size_t) audio_ch * N];
+            for (int i = 0; i < Lh; i++) { p0[i] += ir[1][i]; p0[i] /= 2.0f; }
+        }
+        hipError_t e = hipMemcpyAsync(p->d_time, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, p->stream);
+        if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "upload", hipGetErrorString(e)); break; }
+        rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, batch);
+        if (rc != IRB_OK) break;
+        const int nbins = N / 2 + 1;
+        for (int c = 0; c < audio_ch; c++) {
+            const int irc = (ir_rows == 2) ? c : 0;                   // :318-323
+            irb::k_cmul<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
+                reinterpret_cast<float2 *>(p->d_spec + (size_t) c * 2 * N),
+                reinterpret_cast<const float2 *>(p->d_spec + (size_t) (audio_ch + irc) * 2 * N), nbins);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "k_cmul", hipGetErrorString(e)); break; }
+        rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, audio_ch);
+        if (rc != IRB_OK) break;
+        e = hipMemcpyAsync(host.data(), p->d_time, sizeof(float) * (size_t) audio_ch * N, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
+        for (int c = 0; c < audio_ch; c++) std::memcpy(out[c], &host[(size_t) c * N], sizeof(float) * (size_t) Lout);   // :340-344
+    } while (0);
+    irb_lfft_destroy(p);
+    return rc;
+}
+
+// ---- ir::IRtoRealFFTRaw (fp/ir.cpp:106-147) ------------------------------------------------------------
+int irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows)
+{
+    if (!ir || !out || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    if (!is_pow2(ir_part_size) || ir_part_size < 16 || ir_part_size > 2048)
+        return irb_set_error_(IRB_ERR_ARG, "irPartSize must be a power of two in [16, 2048]");
+    const int bufcount = len / ir_part_size + 1;                      // :107
+    const int N = ir_part_size * 2;                                   // :108
+    if ((long) out_len < (long) bufcount * N) return irb_set_error_(IRB_ERR_ARG, "out too small");
+    std::memset(out, 0, sizeof(float) * (size_t) bufcount * N);       // an untouched last buffer stays zero
+    irb_fdl_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.device = device; cfg.n_instances = 1; cfg.channels = 1; cfg.block = ir_part_size; cfg.max_ir_len = len;
+    cfg.max_blocks_per_call = 1;
+    irb_fdl *h = nullptr;
+    int rc = irb_fdl_create(&cfg, &h);
+    if (rc != IRB_OK) return rc;
+    const float *irp[1] = {ir};
+    rc = irb_fdl_set_ir(h, 0, irp, 1, len);
+    const int np = (len + ir_part_size - 1) / ir_part_size;
+    if (rc == IRB_OK) rc = irb_fdl_get_ir_spectra(h, 0, 0, out, np);
+    irb_fdl_destroy(h);
+    if (rc == IRB_OK && n_rows) *n_rows = bufcount;
+    return rc;
+}
+
 }  // extern "C"

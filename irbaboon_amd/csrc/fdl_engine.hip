@@ -366,6 +366,46 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
     return IRB_OK;
 }
 
+int irb_fdl_get_ir_spectra(irb_fdl *h, int instance, int channel, float *spectra, int n_partitions)
+{
+    if (!h || !spectra) return fail(IRB_ERR_ARG, "null argument");
+    if (instance < 0 || instance >= h->I || channel < 0 || channel >= h->C) return fail(IRB_ERR_ARG, "instance/channel out of range");
+    const int set = h->h_set_of_stream[instance * h->C + channel];
+    if (n_partitions < 0 || n_partitions > h->h_np_of_set[set])
+        return fail(IRB_ERR_ARG, "n_partitions %d exceeds the %d partitions held", n_partitions, h->h_np_of_set[set]);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(spectra, h->d_H + (size_t) set * h->Ppad * h->M, sizeof(float2) * (size_t) n_partitions * h->M,
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
+int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra, int ir_channels, int n_partitions)
+{
+    if (!h || !spectra) return fail(IRB_ERR_ARG, "null argument");
+    if (instance < 0 || instance >= h->I) return fail(IRB_ERR_ARG, "instance %d out of range", instance);
+    if (n_partitions < 0 || n_partitions > h->P) return fail(IRB_ERR_ARG, "n_partitions %d exceeds capacity %d", n_partitions, h->P);
+    if (!((ir_channels == 1 || (ir_channels == 2 && h->C == 2)) && (h->C == 1 || h->C == 2)))
+        return fail(IRB_ERR_LAYOUT, "spectra for %d IR channels cannot feed %d audio channels", ir_channels, h->C);
+    HIP_TRY(hipSetDevice(h->device));
+    const int first_set = instance * h->C, np = n_partitions;
+    for (int r = 0; r < ir_channels; r++) {
+        if (!spectra[r] && np > 0) return fail(IRB_ERR_ARG, "spectra[%d] is null", r);
+        float2 *dst = h->d_H + (size_t) (first_set + r) * h->Ppad * h->M;
+        if (np > 0) HIP_TRY(hipMemcpyAsync(dst, spectra[r], sizeof(float2) * (size_t) np * h->M, hipMemcpyHostToDevice, h->stream));
+        const int np_pad = std::min((np + kTT - 1) / kTT * kTT, h->Ppad);
+        if (np_pad > np) HIP_TRY(hipMemsetAsync(dst + (size_t) np * h->M, 0, sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
+    }
+    for (int c = 0; c < h->C; c++) {
+        h->h_set_of_stream[first_set + c] = first_set + (ir_channels == 2 ? c : 0);
+        h->h_np_of_set[first_set + c] = np;
+    }
+    int rc = upload_maps(h);
+    if (rc != IRB_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IRB_OK;
+}
+
 int irb_fdl_reset(irb_fdl *h)
 {
     if (!h) return fail(IRB_ERR_ARG, "null handle");

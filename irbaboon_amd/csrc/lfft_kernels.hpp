@@ -175,4 +175,13 @@ __global__ __launch_bounds__(256) void k_cdiv(float2 *__restrict__ num, const fl
     num[i] = make_float2((a * c + b * d) / den2, (b * c - a * d) / den2);
 }
 
+// tools::complexMul over bins 0..N/2 (reference fp/convolution.cpp:326-331, fp/tools.cpp:44-52): a *= h
+__global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const float2 *__restrict__ h, int nbins)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    const float2 x = a[i], c = h[i];
+    a[i] = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
+}
+
 }  // namespace irb

@@ -50,6 +50,20 @@ class FdlEngine:
         assert s.size == self.block
         check(_lib.lib().irb_fdl_set_ir_partition(self._h, instance, partition, s.ctypes.data_as(fp)))
 
+    def get_ir_spectra(self, instance, channel, n_partitions):
+        """[n_partitions][N] float32: packed partition spectra (im(0) := re(N/2), fp/ir.cpp:123-124)."""
+        out = np.empty((n_partitions, self.info.fft_len), np.float32)
+        check(_lib.lib().irb_fdl_get_ir_spectra(self._h, instance, channel, out.ctypes.data_as(fp), n_partitions))
+        return out
+
+    def set_ir_spectra(self, instance, spectra):
+        """spectra: float32 [ir_channels][n_partitions][N] (or [n_partitions][N] for mono)."""
+        sp = np.ascontiguousarray(spectra, np.float32)
+        if sp.ndim == 2:
+            sp = sp[None]
+        flat = sp.reshape(sp.shape[0], -1)
+        check(_lib.lib().irb_fdl_set_ir_spectra(self._h, instance, planar_ptrs(flat), sp.shape[0], sp.shape[1]))
+
     def reset(self):
         check(_lib.lib().irb_fdl_reset(self._h))
 

@@ -115,3 +115,74 @@ def test_config5_full_size_one_million_samples():
     ref = oracle.deconvolve(cap, sweep, sr, smoothing=False)
     R = np.fft.rfft(ref.astype(np.float64))
     assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
+
+
+# ---- SURVEY section 8(f) ranks 3 and 4 ----------------------------------------------------------------
+import os  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "convolve_cases.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in GOLD.files}))
+def test_convolve_nonperiodic_matches_golden_and_oracle(name):
+    audio, ir = GOLD[name + "/audio"], GOLD[name + "/ir"]
+    exp = GOLD[name + "/expected_f64"]
+    y = ib.convolveNonPeriodic(audio, ir)
+    ref, _ = oracle.convolve_nonperiodic(audio, ir)
+    assert y.shape == exp.shape
+    for c in range(y.shape[0]):
+        assert rel_rms(y[c], exp[c]) < 1e-5 and rel_rms(y[c], ref[c]) < 1e-5
+
+
+def test_convolve_nonperiodic_layout_and_empty():
+    y = ib.convolveNonPeriodic(np.ones((3, 64), np.float32), np.ones((1, 16), np.float32))
+    assert y.shape == (3, 79) and not y.any()
+    assert not ib.convolveNonPeriodic(np.zeros((1, 0), np.float32), np.ones((1, 16), np.float32)).any()
+
+
+def test_convolve_nonperiodic_long():
+    x, h = white_noise(1, 700000)[None], decaying_ir(2, 300000)[None]
+    import scipy.signal
+    y = ib.convolveNonPeriodic(x, h)
+    assert rel_rms(y[0], scipy.signal.fftconvolve(x[0].astype(np.float64), h[0].astype(np.float64))) < 1e-5
+
+
+@pytest.mark.parametrize("n,ps", [(2048, 256), (2000, 256), (700, 64), (96000, 512)])
+def test_ir_to_real_fft_raw_layout(n, ps):
+    """ir::IRtoRealFFTRaw (fp/ir.cpp:106-147): len/ps + 1 rows of 2*ps floats, each the partition's FFT with
+    im(0) := re(N/2); an exact multiple leaves a trailing all-zero row."""
+    h = decaying_ir(n, n)
+    raw = ib.IRtoRealFFTRaw(h, ps)
+    assert raw.shape == (n // ps + 1, 2 * ps)
+    N = 2 * ps
+    for k in range((n + ps - 1) // ps):
+        part = np.zeros(N)
+        seg = h[k * ps:(k + 1) * ps]
+        part[:seg.size] = seg
+        F = np.fft.rfft(part)
+        row = raw[k].astype(np.float64)
+        got = row[0::2] + 1j * row[1::2]
+        assert abs(got[0].real - F[0].real) < 1e-5 and abs(got[0].imag - F[ps].real) < 1e-5
+        assert np.abs(got[1:] - F[1:ps]).max() < 1e-5
+        # same numbers as the oracle's fftTransform of the partition, packed
+        o = oracle.fft_transform(part.astype(np.float32))
+        assert abs(row[1] - o[N]) < 1e-5 and np.abs(row[2:] - o[2:N]).max() < 1e-5
+    if n % ps == 0:
+        assert not raw[-1].any()
+
+
+def test_ir_spectra_roundtrip_through_engine():
+    """spectra exported by one engine and uploaded into another give the same convolution."""
+    B, Lh, T = 128, 1000, 12
+    irs = np.stack([decaying_ir(1, Lh), decaying_ir(2, Lh)])
+    x = np.stack([white_noise(3, T * B), white_noise(4, T * B)])
+    with ib.FdlEngine(1, 2, B, Lh) as a, ib.FdlEngine(1, 2, B, Lh) as b:
+        a.set_ir(0, irs)
+        ya = a.process(x)
+        P = a.info.partitions
+        sp = np.stack([a.get_ir_spectra(0, c, P) for c in range(2)])
+        assert sp.shape == (2, P, 2 * B)
+        b.set_ir_spectra(0, sp)
+        assert np.array_equal(b.process(x), ya)
+        raw = ib.IRtoRealFFTRaw(irs[0], B)
+        assert np.allclose(raw[:P], sp[0], atol=1e-6)

@@ -46,7 +46,37 @@ def single(B=256, Lh=96000, n=2000, flags=0):
     print(f"single stream B={B} Lh={Lh} splits={eng.info.splits}: device {ms/n*1e3:.2f} us/block, host-inclusive {wall/n*1e6:.2f} us/block")
 
 
+def lfft(logn=20, batch=1, reps=50):
+    """device-resident large real FFT: forward and inverse, and the full one-shot deconvolve vs the oracle"""
+    import irbaboon_amd as ib
+    N = 1 << logn
+    plan = ib.LargeFft(N, batch)
+    plan.forward(batch); plan.inverse(batch); plan.synchronize()
+    plan.mark(0)
+    for _ in range(reps):
+        plan.forward(batch)
+    plan.mark(1)
+    f = plan.elapsed_ms() / reps
+    plan.mark(0)
+    for _ in range(reps):
+        plan.inverse(batch)
+    plan.mark(1)
+    i = plan.elapsed_ms() / reps
+    # minimum traffic: read N floats + write N+2 floats (forward)
+    print(f"lfft N=2^{logn} batch={batch}: forward {f*1e3:.1f} us, inverse {i*1e3:.1f} us, "
+          f"effective {batch*8.0*N/f/1e6:.1f} GB/s (forward, min traffic 8N bytes)")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle
+    from irbaboon_amd.synth import exp_sine_sweep
+    sweep = exp_sine_sweep(3 * N // 4, 48000, 20.0, 24000, fade_from=22000, n_total=N)
+    cap = np.roll(sweep, 100) * 0.5
+    for smoothing in (False, True):
+        t0 = time.perf_counter(); ib.deconvolve(cap, sweep, 48000, smoothing); g = time.perf_counter() - t0
+        t0 = time.perf_counter(); oracle.deconvolve(cap, sweep, 48000, smoothing); c = time.perf_counter() - t0
+        print(f"deconvolve N=2^{logn} smoothing={smoothing}: GPU path {g*1e3:.1f} ms (incl. plan + PCIe + host smoothing), oracle CPU {c*1e3:.1f} ms")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft}[mode](*args)
