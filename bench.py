@@ -47,6 +47,64 @@ def cpu_baseline(seconds):
             "sample": f"1 mono stream, B={B}, Lh={LH}, La={La} samples ({La // B}+375 block steps), {dt:.1f} s"}
 
 
+def _timed_calls(eng, d_in, d_out, stride, T, reps):
+    eng.process_device(d_in, d_out, stride, T)
+    eng.synchronize()
+    eng.mark(0)
+    for _ in range(reps):
+        eng.process_device(d_in, d_out, stride, T)
+    eng.mark(1)
+    return eng.elapsed_ms() / reps
+
+
+def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
+    """The other BASELINE.json configurations, measured the same way (device-resident audio, hipEvents);
+    parity for each is covered by tests/.  Not part of `value`."""
+    res = {}
+
+    def run(name, I, C, Bk, Lh, T, reps, note):
+        e = FdlEngine(I, C, Bk, Lh, max_blocks_per_call=T, device=dev)
+        for i in range(I):
+            e.set_ir(i, np.stack([decaying_ir(27000 + 2 * i + c, Lh) for c in range(C)]))
+        di, do, st = e.device_io()
+        e.upload(di, np.stack([white_noise(3000 + s, T * Bk) for s in range(I * C)]))
+        ms = _timed_calls(e, di, do, st, T, reps)
+        alg = I * C * T * e.info.algorithmic_bytes_per_block_step
+        res[name] = {"Msamples_per_s": round(I * C * T * Bk / ms / 1e3, 1), "ms_per_call": round(ms, 4), "blocks_per_call": T,
+                     "algorithmic_GBps_streaming_model": round(alg / ms / 1e6, 1), "note": note}
+        e.close()
+
+    run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 10,
+        "ONE mono stream, whole 960000-sample signal in one call (time-tiled MAC); cache-resident, compute-bound")
+    run("configs[1]_x2048_8_blocks_per_call", 2048, 1, 256, 96000, 8, 10,
+        "2048 instances, 8 blocks per call: H and FDL rows are read once per 8 outputs")
+    run("configs[2]_stereo_10s_ir_streaming", 1, 2, 128, 480000, 1, 200,
+        "stereo, B=128, P=3750, one block per call (split-P path, 14.6 MiB working set: Infinity-Cache resident)")
+    run("configs[2]_stereo_10s_ir_offline", 1, 2, 128, 480000, 2048, 5, "same IRs, 2048 blocks per call (time-tiled)")
+    run("configs[3]_1024_instances_b512_streaming", 1024, 1, 512, 96000, 1, 100,
+        "1024 mono instances, B=512, P=188, one block per call: HBM-bound (1.5 GiB working set)")
+    import irbaboon_amd as ib
+    plan = ib.LargeFft(1 << 20, 1, device=dev)
+    plan.forward(1)
+    plan.inverse(1)
+    plan.synchronize()
+    plan.mark(0)
+    for _ in range(50):
+        plan.forward(1)
+    plan.mark(1)
+    f = plan.elapsed_ms() / 50
+    plan.mark(0)
+    for _ in range(50):
+        plan.inverse(1)
+    plan.mark(1)
+    i = plan.elapsed_ms() / 50
+    res["configs[4]_2^20_real_fft"] = {"forward_us": round(f * 1e3, 1), "inverse_us": round(i * 1e3, 1),
+                                       "effective_GBps_min_traffic": round(8.0 * (1 << 20) / f / 1e6, 1),
+                                       "note": "single 2^20-point real FFT (four-step, 3 launches); latency-bound"}
+    plan.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +211,10 @@ def main():
                                 "us_per_block": round(dt1 / n1 * 1e6, 2), "splits": one.info.splits,
                                 "note": "one mono stream, one block per step, 1.5 MiB working set (cache-resident)"}
         one.close()
+
+    if ranks.rank == 0 and ranks.world == 1 and not args.no_single:
+        eng.close()
+        out["other_configs"] = other_configs(dev, np, FdlEngine, decaying_ir, white_noise)
 
     if ranks.rank == 0 and ranks.world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
