@@ -61,6 +61,7 @@ struct irb_fdl {
     float2 *d_H = nullptr, *d_X = nullptr, *d_tw = nullptr, *d_part = nullptr;
     float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
     int *d_set_of_stream = nullptr, *d_np_of_set = nullptr;
+    unsigned *d_tickets = nullptr;           // [S] arrival counters of k_step_split
     float *h_io = nullptr;                   // pinned: [S][Tmax*B]
     float *h_ir = nullptr;                   // pinned: [C][P*B]
     int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // pinned mirrors
@@ -94,10 +95,12 @@ int choose_splits(const irb_fdl *h)
     if (h->flags & IRB_FDL_FORCE_FUSED) return 1;
     if (const char *v = std::getenv("IRB_SPLITS")) return std::max(1, std::atoi(v));    // tuning override
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
-    const int by_work = (h->P + stripes * 4 - 1) / (stripes * 4);       // >= 4 rows per stripe and workgroup
-    if (h->flags & IRB_FDL_FORCE_SPLIT) return std::max(2, std::min(by_work, 64));
-    if (h->S >= 128) return 1;                                          // enough workgroups already
-    const int by_chip = std::max(1, 768 / h->S);                        // ~3 workgroups per CU
+    // latency path (few streams): measured optimum is 16..64 workgroups per stream with >= 16 partitions
+    // per stripe; more splits only lengthen the last arriver's slab sum (tools/perf_probe.py single)
+    const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
+    if (h->flags & IRB_FDL_FORCE_SPLIT) return std::max(2, by_work);
+    if (h->S >= 128) return 1;                                          // enough workgroups already: fused kernel
+    const int by_chip = std::max(1, 512 / h->S);
     const int s = std::min(by_work, by_chip);
     return s < 2 ? 1 : s;
 }
@@ -136,6 +139,8 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
         // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
         if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
+        FOR_N(h->N, irb::k_step_split<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets));
     } else {
         FOR_N(h->N, irb::k_push_fft<NN><<<dim3((h->S + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
         FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a));
@@ -194,7 +199,7 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
-    (void) hipFree(h->d_set_of_stream); (void) hipFree(h->d_np_of_set);
+    (void) hipFree(h->d_set_of_stream); (void) hipFree(h->d_np_of_set); (void) hipFree(h->d_tickets);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
@@ -228,6 +233,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->flags = cfg->flags;
     h->splits = choose_splits(h);
     h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
+    if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
 
     int rc = IRB_OK;
@@ -258,6 +264,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (!guard(dev_alloc(h, &h->d_irtime, (size_t) h->C * h->P * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_set_of_stream, (size_t) h->S))) break;
         if (!guard(dev_alloc(h, &h->d_np_of_set, (size_t) h->S))) break;
+        if (!guard(dev_alloc(h, &h->d_tickets, (size_t) h->S))) break;
         hipError_t e;
         if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) h->S * h->Tmax * h->B)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B)) != hipSuccess ||
@@ -276,6 +283,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * SM * h->Ppad, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * (size_t) h->S, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_in, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_out, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "device init: %s", hipGetErrorString(e));

@@ -364,6 +364,96 @@ __global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_step_split: the split path in ONE launch.  grid = S*splits.  Workgroup (s, j) sums its partition
+// range into a slab; split 0 also transforms the new block (only its range contains partition 0).
+// The last workgroup of a stream to arrive (ticket counter, no waiting anywhere) adds the slabs and does
+// the inverse FFT + overlap-add.  Hand-off follows the counter form of the agent-scope release/acquire
+// protocol (cdna_hip_programming.md Guideline 16): plain slab stores, every wave drains vmcnt, workgroup
+// barrier, one lane: release fence + drained wait + relaxed agent-scope ticket; the last arriver: acquire
+// fence + wait + barrier, then plain loads.  The counter is zeroed at create and re-zeroed by the last
+// arriver (the next launch is stream-ordered behind this one).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *__restrict__ tickets)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2;
+    __shared__ Lds<N> lds;
+    __shared__ unsigned l_ticket;
+    const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int set = a.set_of_stream[s];
+    const int np = a.np_of_set[set];
+    const int kb = (int) ((long) np * j / a.splits), ke = (int) ((long) np * (j + 1) / a.splits);
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    float2 *Xs = a.X + (size_t) s * a.R * M;
+    const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
+
+    stage_twiddles<N>(a.tw, lds.tw);
+    if (j == 0 && wave == 0) wave_load_block<M>(a.in + (size_t) s * a.in_stride, a.B, lds.buf, lane);
+
+    float4 acc[G::CPT];
+#pragma unroll
+    for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 dc = make_float2(0.f, 0.f);
+    mac_range<N, 4>(H4, X4, (j == 0 && kb == 0) ? 1 : kb, ke, a.head, a.R, acc, dc);
+    __syncthreads();                                   // twiddles (and split 0's block) are in LDS
+
+    if (j == 0) {
+        if (wave == 0) {
+            wave_fft<M, false>(lds.buf, lds.tw, lane);
+            float2 *ring = Xs + (size_t) a.head * M;
+            wave_split_forward<M>(lds.buf, lds.tw, lane, [&](int b, float2 v) { lds.scratch[b] = v; ring[b] = v; });
+        }
+        __syncthreads();
+        if (ke > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
+            const int col = threadIdx.x;
+#pragma unroll
+            for (int c = 0; c < G::CPT; c++) {
+                const float4 h = H4[col + c * G::LW];
+                const float4 x = reinterpret_cast<const float4 *>(lds.scratch)[col + c * G::LW];
+                if (c == 0) { dc.x += x.x * h.x; dc.y += x.y * h.y; }
+                acc[c].x += x.x * h.x - x.y * h.y;
+                acc[c].y += x.x * h.y + x.y * h.x;
+                acc[c].z += x.z * h.z - x.w * h.w;
+                acc[c].w += x.z * h.w + x.w * h.z;
+            }
+        }
+        __syncthreads();
+    }
+
+    reduce_stripes<N>(acc, dc, lds.scratch, lds.buf);
+    float2 *slab = a.part + ((size_t) s * a.splits + j) * M;
+    for (int b = threadIdx.x; b < M; b += kThreads) slab[b] = lds.buf[b];
+
+    // ---- publish the slab, take a ticket ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        l_ticket = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (l_ticket != (unsigned) (a.splits - 1)) return;
+
+    // ---- last arriver of this stream: combine ----
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&tickets[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    sum_partials<N>(a.part + (size_t) s * a.splits * M, a.splits, lds.scratch, lds.buf);
+    if (wave == 0) {
+        wave_split_inverse<M>(lds.buf, lds.tw, lane);
+        wave_fft<M, true>(lds.buf, lds.tw, lane);
+        wave_overlap_add(reinterpret_cast<const float *>(lds.buf), 1.0f / (float) N, a.B,
+                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Time-tiled path: a call that carries T > 1 new blocks per stream (host blocks larger than B, or the
 // whole signal in the offline function).  All T input spectra are pushed first, then every output
 //   Y_{j}[b] = sum_k X_{t0+j-k}[b] * H_k[b],  j = 0..T-1

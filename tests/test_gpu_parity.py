@@ -39,7 +39,8 @@ ENGINE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_SPLIT, 0], ids=["fused", "split", "auto"])
+@pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, 0],
+                         ids=["fused", "split", "split3", "auto"])
 @pytest.mark.parametrize("case", ENGINE_CASES, ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
 def test_engine_streaming_matches_oracle(case, flags):
     I, C, Cir, B, Lh, T = case
