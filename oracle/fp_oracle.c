@@ -134,6 +134,7 @@ static void fft_complex(const fp_fft *f, const cpx *in, cpx *out, int inverse)
 void fp_fft_forward_real(const fp_fft *f, float *d)
 {
     const int n = f->n;
+    if (n == 1) return;                      /* the engine's own early-out for a 1-point transform */
     for (int i = 0; i < n; i++) { f->scratch[i].re = d[i]; f->scratch[i].im = 0.0f; }
     fft_complex(f, f->scratch, (cpx *) d, 0);
 }
@@ -141,6 +142,7 @@ void fp_fft_forward_real(const fp_fft *f, float *d)
 void fp_fft_inverse_real(const fp_fft *f, float *d)
 {
     const int n = f->n;
+    if (n == 1) return;
     cpx *in = (cpx *) d;
     for (int i = n >> 1; i < n; i++) { in[i].re = in[n - i].re; in[i].im = -in[n - i].im; }
     fft_complex(f, in, f->scratch, 1);

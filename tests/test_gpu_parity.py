@@ -241,3 +241,43 @@ def test_device_resident_path_and_event_timer():
         assert eng.elapsed_ms() > 0.0
         y = eng.download(d_out, I * stride).reshape(I, stride)
         assert np.array_equal(y, ref)
+
+
+# ---- randomized shapes (hypothesis): ragged lengths, tiny and non-power-of-two blocks, all layouts ----
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(B=st.integers(2, 300), Lh=st.integers(1, 3000), La=st.integers(0, 6000),
+       ac=st.integers(1, 2), ic=st.integers(1, 2), seed=st.integers(0, 10 ** 6))
+def test_convolve_periodic_random_shapes(B, Lh, La, ac, ic, seed):
+    audio = np.stack([white_noise(seed + c, La) for c in range(ac)]) if La else np.zeros((ac, 0), np.float32)
+    ir = np.stack([decaying_ir(seed + 10 + c, Lh) for c in range(ic)])
+    y = convolvePeriodic(audio, ir, B)
+    ref, rc = oracle.convolve_periodic(audio, ir, B)
+    assert rc == 0 and y.shape == ref.shape
+    nw = written_samples(La, Lh, B)
+    for c in range(ac):
+        if np.any(ref[c, :nw]):
+            assert rel_rms(y[c, :nw], ref[c, :nw]) < RMS_TOL
+        else:
+            assert np.abs(y[c, :nw]).max(initial=0.0) < 1e-6
+    assert not y[:, nw:].any()
+
+
+@settings(max_examples=15, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(I=st.integers(1, 5), C=st.integers(1, 2), B=st.sampled_from([8, 32, 100, 128, 256]), Lh=st.integers(1, 2500),
+       T=st.integers(1, 20), Tmax=st.integers(1, 9), seed=st.integers(0, 10 ** 6))
+def test_engine_random_shapes_and_call_sizes(I, C, B, Lh, T, Tmax, seed):
+    """any split of the same audio into process calls gives the same stream (streaming == tiled path)"""
+    x = _streams(I, C, T * B, seed)
+    irs = [np.stack([decaying_ir(seed + 50 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=Tmax) as eng:
+        for i in range(I):
+            eng.set_ir(i, irs[i])
+        y = eng.process(x)
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(y[i * C + c], ref[c, :T * B]) < RMS_TOL

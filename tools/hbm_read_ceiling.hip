@@ -1,0 +1,76 @@
+// hbm_read_ceiling.hip -- what a pure streaming READ of the bench's footprint reaches on this MI355X:
+// the practical ceiling for k_step_fused (which is >99.7 % reads).  Each workgroup reads two contiguous
+// 768 KB regions (like one stream's H and FDL) with 16-byte loads, sums them, writes one float.
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/hbm_read_ceiling tools/hbm_read_ceiling.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_read(const v4f *__restrict__ a, const v4f *__restrict__ b, float *out, int rows /*float4 per region*/)
+{
+    const v4f *pa = a + (size_t) blockIdx.x * rows, *pb = b + (size_t) blockIdx.x * rows;
+    v4f acc = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i + (U - 1) * 256 < rows; i += U * 256) {
+        v4f x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            x[u] = NT ? __builtin_nontemporal_load(pa + i + u * 256) : pa[i + u * 256];
+            y[u] = NT ? __builtin_nontemporal_load(pb + i + u * 256) : pb[i + u * 256];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += x[u] * y[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+}
+// linear grid-stride stream of the same bytes: the friendliest possible pattern
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear(const v4f *__restrict__ a, float *out, size_t n)
+{
+    v4f acc = {0, 0, 0, 0};
+    const size_t stride = (size_t) gridDim.x * 256 * 4;
+    for (size_t i = (size_t) blockIdx.x * 256 * 4 + threadIdx.x; i + 3 * 256 < n; i += stride) {
+        v4f x0 = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        v4f x1 = NT ? __builtin_nontemporal_load(a + i + 256) : a[i + 256];
+        v4f x2 = NT ? __builtin_nontemporal_load(a + i + 512) : a[i + 512];
+        v4f x3 = NT ? __builtin_nontemporal_load(a + i + 768) : a[i + 768];
+        acc += x0 + x1 + x2 + x3;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+}
+int main()
+{
+    const int S = 2048, rows = 375 * 128;            // 375 rows of 2 KB = 128 float4
+    const size_t n = (size_t) S * rows;
+    v4f *a, *b; float *o;
+    hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&o, S * 4);
+    hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](auto kern, const char *name) {
+        for (int i = 0; i < 5; i++) kern<<<S, 256>>>(a, b, o, rows);
+        hipEventRecord(e0);
+        for (int i = 0; i < 50; i++) kern<<<S, 256>>>(a, b, o, rows);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-24s %.1f GB/s (%.4f ms per pass of %.3f GB)\n", name, 2.0 * n * 16 / (ms / 50 * 1e-3) / 1e9, ms / 50, 2.0 * n * 16 / 1e9);
+    };
+    run(k_read<false, 2>, "default loads, U=2");
+    run(k_read<true, 2>, "non-temporal, U=2");
+    run(k_read<true, 4>, "non-temporal, U=4");
+    run(k_read<false, 4>, "default loads, U=4");
+    run(k_read<true, 2>, "non-temporal, U=2");
+    auto runl = [&](auto kern, int grid, const char *name) {
+        for (int i = 0; i < 5; i++) kern<<<grid, 256>>>(a, o, n);
+        hipEventRecord(e0);
+        for (int i = 0; i < 50; i++) kern<<<grid, 256>>>(a, o, n);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-24s grid %5d: %.1f GB/s\n", name, grid, 1.0 * n * 16 / (ms / 50 * 1e-3) / 1e9);
+    };
+    runl(k_linear<true>, 2048, "linear nt");
+    runl(k_linear<false>, 2048, "linear default");
+    runl(k_linear<true>, 4096, "linear nt");
+    runl(k_linear<true>, 1024, "linear nt");
+    runl(k_linear<true>, 8192, "linear nt");
+    return 0;
+}
