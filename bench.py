@@ -62,10 +62,10 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     parity for each is covered by tests/.  Not part of `value`."""
     res = {}
 
-    def run(name, I, C, Bk, Lh, T, reps, note):
+    def run(name, I, C, Bk, Lh, T, reps, note, ir_ch=None):
         e = FdlEngine(I, C, Bk, Lh, max_blocks_per_call=T, device=dev)
         for i in range(I):
-            e.set_ir(i, np.stack([decaying_ir(27000 + 2 * i + c, Lh) for c in range(C)]))
+            e.set_ir(i, np.stack([decaying_ir(27000 + 2 * i + c, Lh) for c in range(ir_ch or C)]))
         di, do, st = e.device_io()
         e.upload(di, np.stack([white_noise(3000 + s, T * Bk) for s in range(I * C)]))
         ms = _timed_calls(e, di, do, st, T, reps)
@@ -83,6 +83,9 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     run("configs[2]_stereo_10s_ir_offline", 1, 2, 128, 480000, 2048, 5, "same IRs, 2048 blocks per call (time-tiled)")
     run("configs[3]_1024_instances_b512_streaming", 1024, 1, 512, 96000, 1, 100,
         "1024 mono instances, B=512, P=188, one block per call: HBM-bound (1.5 GiB working set)")
+    run("rt_layout_1024_stereo_instances_mono_ir", 1024, 2, 256, 96000, 1, 100,
+        "stereo audio, IR channel 0 for both channels (the plug-in's real-time layout, Source/PluginProcessor.cpp:485): "
+        "paired kernel loads each IR row once for both channels (3 rows per partition instead of 4)", ir_ch=1)
     import irbaboon_amd as ib
     plan = ib.LargeFft(1 << 20, 1, device=dev)
     plan.forward(1)

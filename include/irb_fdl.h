@@ -44,6 +44,7 @@ extern "C" {
 #define IRB_FDL_FORCE_FUSED   0x1u  /* always one workgroup per stream               */
 #define IRB_FDL_FORCE_SPLIT   0x2u  /* always split the partitions over workgroups   */
 #define IRB_FDL_SPLIT_3LAUNCH 0x4u  /* split path as three launches (no in-kernel hand-off) */
+#define IRB_FDL_NO_PAIRING    0x8u  /* never share IR rows between the two channels of an instance */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */

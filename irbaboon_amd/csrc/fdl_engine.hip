@@ -51,6 +51,7 @@ struct irb_fdl {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
+    bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
@@ -137,7 +138,11 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
     if (h->splits <= 1) {
         // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
         // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
-        if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        if (h->pair && h->N <= 2048) {
+            if (h->nt) { FOR_N(h->N, irb::k_step_fused_pair<NN, true><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+            else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        }
+        else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
         FOR_N(h->N, irb::k_step_split<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets));
@@ -179,6 +184,8 @@ int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int firs
 
 int upload_maps(irb_fdl *h)
 {
+    h->pair = (h->C == 2) && !(h->flags & IRB_FDL_NO_PAIRING);
+    for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
     HIP_TRY(hipMemcpyAsync(h->d_set_of_stream, h->h_set_of_stream, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_np_of_set, h->h_np_of_set, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
     return IRB_OK;

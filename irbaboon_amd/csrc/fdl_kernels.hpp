@@ -257,6 +257,140 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_step_fused_pair: the fused step for TWO streams that multiply with the SAME IR spectra -- stereo audio
+// with a mono IR (IRMonoAudioStereo, reference fp/convolution.cpp:32-33,176-181) and the real-time path,
+// which feeds IR channel 0 to both channels (Source/PluginProcessor.cpp:485).  One workgroup per instance:
+// every H row is loaded once and used for both channels, so the step streams 3 rows per partition instead
+// of 4 (-25 % HBM bytes).  Waves 0 and 1 run the two channels' FFTs side by side.  grid = S/2.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct LdsPair {
+    static constexpr int M = N / 2;
+    float2 tw[N / 2];
+    float2 buf[2][M];
+    float2 scratch[2][MacGeom<N>::STRIPES * M];
+};
+
+__device__ __forceinline__ void cmac_pair(float4 &acc, float2 &dc, const float4 x, const float4 h, bool first)
+{
+    if (first) { dc.x += x.x * h.x; dc.y += x.y * h.y; }
+    acc.x += x.x * h.x - x.y * h.y;
+    acc.y += x.x * h.y + x.y * h.x;
+    acc.z += x.z * h.z - x.w * h.w;
+    acc.w += x.z * h.w + x.w * h.z;
+}
+
+template <int N, bool NT>
+__global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2, U = 2;
+    __shared__ LdsPair<N> lds;
+    const int s0 = 2 * blockIdx.x;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int set = a.set_of_stream[s0];
+    const int np = a.np_of_set[set];
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    float2 *Xs[2] = {a.X + (size_t) s0 * a.R * M, a.X + (size_t) (s0 + 1) * a.R * M};
+    const float4 *X4[2] = {reinterpret_cast<const float4 *>(Xs[0]), reinterpret_cast<const float4 *>(Xs[1])};
+    const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
+
+    constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
+    constexpr int ZPL = M > kWave ? M / kWave : 1;
+    float2 twr[TWPT];
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) {
+        const int idx = threadIdx.x + i * kThreads;
+        twr[i] = idx < N / 2 ? a.tw[idx] : make_float2(0.f, 0.f);
+    }
+    float2 zr[ZPL];
+    if (wave < 2) {
+        const float *x = a.in + (size_t) (s0 + wave) * a.in_stride;
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = 2 * (lane + i * kWave);
+            zr[i] = make_float2(n < a.B ? x[n] : 0.0f, n + 1 < a.B ? x[n + 1] : 0.0f);
+        }
+    }
+
+    float4 acc[2][G::CPT];
+    float2 dc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+    for (int c = 0; c < G::CPT; c++) { acc[0][c] = make_float4(0.f, 0.f, 0.f, 0.f); acc[1][c] = acc[0][c]; }
+    int k = 1 + stripe;
+    for (; k + (U - 1) * G::STRIPES < np; k += U * G::STRIPES) {
+        float4 h[U][G::CPT], x0[U][G::CPT], x1[U][G::CPT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kk = k + u * G::STRIPES;
+            int slot = a.head - kk;
+            if (slot < 0) slot += a.R;
+#pragma unroll
+            for (int c = 0; c < G::CPT; c++) {
+                h[u][c] = ld16<NT>(H4 + (size_t) kk * G::L + col + c * G::LW);
+                x0[u][c] = ld16<NT>(X4[0] + (size_t) slot * G::L + col + c * G::LW);
+                x1[u][c] = ld16<NT>(X4[1] + (size_t) slot * G::L + col + c * G::LW);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int c = 0; c < G::CPT; c++) {
+                cmac_pair(acc[0][c], dc[0], x0[u][c], h[u][c], c == 0);
+                cmac_pair(acc[1][c], dc[1], x1[u][c], h[u][c], c == 0);
+            }
+    }
+    for (; k < np; k += G::STRIPES) {
+        int slot = a.head - k;
+        if (slot < 0) slot += a.R;
+#pragma unroll
+        for (int c = 0; c < G::CPT; c++) {
+            const float4 h = ld16<NT>(H4 + (size_t) k * G::L + col + c * G::LW);
+            cmac_pair(acc[0][c], dc[0], ld16<NT>(X4[0] + (size_t) slot * G::L + col + c * G::LW), h, c == 0);
+            cmac_pair(acc[1][c], dc[1], ld16<NT>(X4[1] + (size_t) slot * G::L + col + c * G::LW), h, c == 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) {
+        const int idx = threadIdx.x + i * kThreads;
+        if (idx < N / 2) lds.tw[idx] = twr[i];
+    }
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = lane + i * kWave;
+            if (n < M) lds.buf[wave][n] = zr[i];
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {       // new blocks: FFT, spectrum to LDS (for partition 0) and into the ring
+        wave_fft<M, false>(lds.buf[wave], lds.tw, lane);
+        float2 *ring = Xs[wave] + (size_t) a.head * M;
+        float2 *sc = lds.scratch[wave];
+        wave_split_forward<M>(lds.buf[wave], lds.tw, lane, [&](int b, float2 v) { sc[b] = v; ring[b] = v; });
+    }
+    __syncthreads();
+    if (np > 0 && threadIdx.x < G::LW) {
+#pragma unroll
+        for (int c = 0; c < G::CPT; c++) {
+            const float4 h = H4[col + c * G::LW];
+            cmac_pair(acc[0][c], dc[0], reinterpret_cast<const float4 *>(lds.scratch[0])[col + c * G::LW], h, c == 0);
+            cmac_pair(acc[1][c], dc[1], reinterpret_cast<const float4 *>(lds.scratch[1])[col + c * G::LW], h, c == 0);
+        }
+    }
+    __syncthreads();
+    reduce_stripes<N>(acc[0], dc[0], lds.scratch[0], lds.buf[0]);
+    reduce_stripes<N>(acc[1], dc[1], lds.scratch[1], lds.buf[1]);
+    if (wave < 2) {
+        wave_split_inverse<M>(lds.buf[wave], lds.tw, lane);
+        wave_fft<M, true>(lds.buf[wave], lds.tw, lane);
+        wave_overlap_add(reinterpret_cast<const float *>(lds.buf[wave]), 1.0f / (float) N, a.B,
+                         a.ovl + (size_t) (s0 + wave) * a.B, a.out + (size_t) (s0 + wave) * a.out_stride, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split path, for few streams with long IRs (one workgroup per stream cannot fill the chip):
 //   k_push_fft        grid = S            new block -> FFT -> ring slot `head`
 //   k_cmac_partial    grid = S*splits     partial sums over a contiguous partition range

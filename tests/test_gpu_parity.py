@@ -281,3 +281,30 @@ def test_engine_random_shapes_and_call_sizes(I, C, B, Lh, T, Tmax, seed):
         ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
         for c in range(C):
             assert rel_rms(y[i * C + c], ref[c, :T * B]) < RMS_TOL
+
+
+@pytest.mark.parametrize("B,Lh", [(256, 3000), (64, 500), (512, 4000), (1024, 3000)])
+def test_paired_kernel_for_shared_ir_matches_unpaired(B, Lh):
+    """stereo audio + mono IR: the paired kernel (H rows loaded once for both channels) against the
+    per-stream kernel and the oracle; mixed sharing falls back to per-stream automatically."""
+    I, T = 3, 10
+    x = _streams(I, 2, T * B, 900)
+    irs = [decaying_ir(950 + i, Lh)[None] for i in range(I)]
+    outs = []
+    for flags in (_lib.FORCE_FUSED, _lib.FORCE_FUSED | _lib.NO_PAIRING):
+        with FdlEngine(I, 2, B, Lh, flags=flags) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            outs.append(eng.process(x))
+    assert rel_rms(outs[0], outs[1]) < 1e-6
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[2 * i:2 * i + 2], irs[i], B)
+        for c in range(2):
+            assert rel_rms(outs[0][2 * i + c], ref[c, :T * B]) < RMS_TOL
+    with FdlEngine(2, 2, B, Lh, flags=_lib.FORCE_FUSED) as eng:          # instance 1 gets a stereo IR: no pairing
+        eng.set_ir(0, irs[0])
+        st = np.stack([decaying_ir(1, Lh), decaying_ir(2, Lh)])
+        eng.set_ir(1, st)
+        y = eng.process(x[:4])
+        ref, _ = oracle.convolve_periodic(x[2:4], st, B)
+        assert rel_rms(y[3], ref[1, :T * B]) < RMS_TOL

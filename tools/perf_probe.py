@@ -46,6 +46,17 @@ def single(B=256, Lh=96000, n=2000, flags=0):
     print(f"single stream B={B} Lh={Lh} splits={eng.info.splits}: device {ms/n*1e3:.2f} us/block, host-inclusive {wall/n*1e6:.2f} us/block")
 
 
+def stereo(I=1024, B=256, Lh=96000, flags=0):
+    """stereo instances with a mono IR (the plug-in's real-time layout), one block per call"""
+    eng = FdlEngine(I, 2, B, Lh, max_blocks_per_call=1, flags=flags)
+    for i in range(I):
+        eng.set_ir(i, decaying_ir(1 + i, Lh))
+    d_in, d_out, stride = eng.device_io()
+    eng.upload(d_in, np.stack([white_noise(5 + s, B) for s in range(2 * I)]))
+    ms = timed(eng, d_in, d_out, stride, 1, 100)
+    print(f"stereo/mono-IR I={I} B={B} Lh={Lh} flags={flags}: {ms*1e3:.1f} us/step  {2*I*B/ms/1e3:.1f} Msamples/s")
+
+
 def lfft(logn=20, batch=1, reps=50):
     """device-resident large real FFT: forward and inverse, and the full one-shot deconvolve vs the oracle"""
     import irbaboon_amd as ib
@@ -79,4 +90,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo}[mode](*args)
