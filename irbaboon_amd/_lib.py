@@ -92,8 +92,12 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO_PATH):
-            raise ImportError(f"{SO_PATH} not built: run `make -C irbaboon_amd/csrc` "
-                              "(or __graft_entry__.build()); there is no CPU fallback")
+            # not a fallback: the only implementation is the HIP library, so build it from source
+            import subprocess
+            r = subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(SO_PATH):
+                raise ImportError(f"{SO_PATH} is missing and `make -C irbaboon_amd/csrc` failed "
+                                  f"(there is no CPU fallback):\n{r.stderr[-2000:]}")
         l = C.CDLL(SO_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(l, name)

@@ -31,6 +31,8 @@ struct irb_rt {
     std::vector<float> ready;                 // [nb][C][B] complete blocks of this call
     std::vector<float> conv;                  // [C][B] one processed block
     std::vector<float> outRing;               // [outSize][C][H] (:210)
+    std::vector<const float *> inp;           // per-channel pointers handed to the engine (sized at create)
+    std::vector<float *> outp;
     int outSize = 0, outRd = 0, outWr = 0;
     int inputBufferSampleIndex = 0, outputBufferSampleIndex = 0, outputSampleIndex = 0;
     int irWriteIndex = 0;                     // irFftBufferArray write index (:457-461)
@@ -61,6 +63,8 @@ int irb_rt_create(int device, int channels, int block, int ir_ring_len, irb_rt *
     p->ir[ir_ring_len > 100 ? 100 : 0] = 1.0f;
     p->inBlock.assign((size_t) channels * block, 0.0f);
     p->conv.assign((size_t) channels * block, 0.0f);
+    p->inp.assign((size_t) channels, nullptr);
+    p->outp.assign((size_t) channels, nullptr);
     *out = p;
     return IRB_OK;
 }
@@ -94,6 +98,9 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     p->outputBufferSampleIndex = 0;                                             // :221
     if (p->outputSampleIndex >= p->H) p->outputSampleIndex = 0;                 // reference: left as is (UB if too large)
     std::fill(p->inBlock.begin(), p->inBlock.end(), 0.0f);
+    // every buffer the audio callback touches is sized here: process_block never allocates
+    p->ready.clear();
+    p->ready.reserve(((size_t) p->H / p->B + 2) * p->C * p->B);
     p->irWriteIndex = 0;                                                        // :226 clearAndResize
     irb_fdl_destroy(p->eng);
     p->eng = nullptr;
@@ -141,8 +148,8 @@ int irb_rt_process_block(irb_rt *p, float *const *buffer, int n)                
 
     // :452-518 one FDL step per complete block, then :525-543 into the output ring
     const size_t nb = p->ready.size() / ((size_t) C * B);
-    std::vector<const float *> inp(C);
-    std::vector<float *> outp(C);
+    std::vector<const float *> &inp = p->inp;
+    std::vector<float *> &outp = p->outp;
     for (size_t j = 0; j < nb; j++) {
         int rc = irb_fdl_set_ir_partition(p->eng, 0, p->irWriteIndex, p->ir.data() + (size_t) p->irWriteIndex * B);   // :455-461
         if (rc != IRB_OK) return rc;
