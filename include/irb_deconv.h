@@ -60,6 +60,10 @@ int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_c
  * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows. */
 int  irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);
 
+/* The one-shot entry points above keep the calling thread's most recent FFT plan (device buffers, twiddle
+ * tables, stream) for reuse; this releases it. */
+void irb_release_cached_plans(void);
+
 /* ---- reusable plan with device-resident buffers (bench, repeated transforms) ---- */
 int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
 void irb_lfft_destroy(irb_lfft *p);

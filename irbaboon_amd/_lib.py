@@ -72,6 +72,7 @@ SYMBOLS = [
     ("irb_invert_filter", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int]),
     ("irb_convolve_nonperiodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, fpp]),
     ("irb_ir_to_real_fft_raw", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]),
+    ("irb_release_cached_plans", None, []),
     ("irb_lfft_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_lfft_destroy", None, [C.c_void_p]),
     ("irb_lfft_buffers", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

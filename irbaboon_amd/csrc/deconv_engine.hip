@@ -106,7 +106,35 @@ int complex_fft(irb_lfft *p, const float2 *src, float2 *tmp, float2 *dst, int ba
 
 }  // namespace
 
+// One-shot entry points (fftTransform, deconvolve, ...) reuse the most recent plan of the calling thread when
+// device, length and batch capacity fit: plan creation (stream, tables, five hipMallocs) costs far more than a
+// 2^20-point transform.  The cached plan is released by irb_release_cached_plans() (or with the process).
+struct PlanCache {
+    irb_lfft *plan = nullptr;      // deliberately no destructor: at process exit the HIP runtime may already be gone
+};
+thread_local PlanCache g_cache;
+
+extern "C" void irb_lfft_destroy(irb_lfft *p);
+extern "C" int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);
+
+int cached_plan(int device, int N, int batch, irb_lfft **out)
+{
+    irb_lfft *p = g_cache.plan;
+    if (p && p->device == device && p->N == N && p->max_batch >= batch) { *out = p; return IRB_OK; }
+    if (p) { irb_lfft_destroy(p); g_cache.plan = nullptr; }
+    int rc = irb_lfft_create(device, N, batch, &p);
+    if (rc != IRB_OK) return rc;
+    g_cache.plan = p;
+    *out = p;
+    return IRB_OK;
+}
+
 extern "C" {
+
+void irb_release_cached_plans(void)
+{
+    if (g_cache.plan) { irb_lfft_destroy(g_cache.plan); g_cache.plan = nullptr; }
+}
 
 int irb_next_power_of_two(int x)                       // tools::nextPowerOfTwo, fp/tools.cpp:180-196
 {
@@ -247,7 +275,7 @@ int irb_fft_transform(int device, const float *in, int len, float *out)
     const int N = std::max(32, irb_next_power_of_two(len));
     if (N != irb_next_power_of_two(len)) return irb_set_error_(IRB_ERR_ARG, "buffers shorter than 17 samples are not supported");
     irb_lfft *p = nullptr;
-    int rc = irb_lfft_create(device, N, 1, &p);
+    int rc = cached_plan(device, N, 1, &p);
     if (rc != IRB_OK) return rc;
     hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * N, p->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_time, in, sizeof(float) * len, hipMemcpyHostToDevice, p->stream);
@@ -255,7 +283,6 @@ int irb_fft_transform(int device, const float *in, int len, float *out)
     if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_spec, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
     if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "irb_fft_transform", hipGetErrorString(e));
-    irb_lfft_destroy(p);
     return rc;
 }
 
@@ -265,14 +292,13 @@ int irb_fft_inv_transform(int device, const float *in, int fft_size, float *out)
     if (!in || !out || fft_size < 64 || !is_pow2(fft_size)) return irb_set_error_(IRB_ERR_ARG, "fft_size must be a power of two >= 64");
     const int N = fft_size / 2;
     irb_lfft *p = nullptr;
-    int rc = irb_lfft_create(device, N, 1, &p);
+    int rc = cached_plan(device, N, 1, &p);
     if (rc != IRB_OK) return rc;
     hipError_t e = hipMemcpyAsync(p->d_spec, in, sizeof(float) * fft_size, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, 1);
     if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_time, sizeof(float) * N, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
     if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "irb_fft_inv_transform", hipGetErrorString(e));
-    irb_lfft_destroy(p);
     return rc;
 }
 
@@ -303,26 +329,29 @@ void irb_averaging_filter(float *buffer, int fft_size, double octave_fraction, d
     const double freqPerBin = (sample_rate / 2) / (double) (N / 2);
     for (int bin = 0; bin <= N; bin += 2)
         oldAmpl[bin / 2] = (float) std::sqrt(std::pow((double) buffer[bin], 2.0) + std::pow((double) buffer[bin + 1], 2.0));
+    // Same values, same order as the reference loop -- only loop-invariant work is hoisted: pow(2, fract) is a
+    // constant, and the log of a bin's amplitude is needed when it enters and when it leaves the window.
+    const double up = std::pow(2.0, fractPerSide);
+    std::vector<float> logAmpl;
+    if (log_avg) {
+        logAmpl.resize(oldAmpl.size());
+        for (size_t i = 0; i < oldAmpl.size(); i++) {
+            float v = oldAmpl[i];
+            round_to_1e16(&v);
+            logAmpl[i] = std::log(v);
+        }
+    }
     float runningSum = 0.0f;
     int prevLowerBin = 0, prevUpperBin = -2;
     for (int bin = 0; bin <= N; bin += 2) {
         const double binFreq = (bin / 2) * freqPerBin;
-        const int lowerBin = 2 * (int) std::round((binFreq / std::pow(2.0, fractPerSide)) / freqPerBin);
-        const int upperBin = 2 * (int) std::round((binFreq * std::pow(2.0, fractPerSide)) / freqPerBin);
+        const int lowerBin = 2 * (int) std::round((binFreq / up) / freqPerBin);
+        const int upperBin = 2 * (int) std::round((binFreq * up) / freqPerBin);
         const double binRangeLength = (double) (upperBin - lowerBin) / 2.0 + 1.0;
         if (log_avg) {
-            for (int sb = prevLowerBin; sb < lowerBin; sb += 2) {
-                float v = oldAmpl[sb / 2];
-                round_to_1e16(&v);
-                runningSum -= std::log(v);
-            }
-            for (int ab = prevUpperBin + 2; ab <= upperBin; ab += 2) {
-                if (ab < fft_size) {
-                    float v = oldAmpl[ab / 2];
-                    round_to_1e16(&v);
-                    runningSum += std::log(v);
-                }
-            }
+            for (int sb = prevLowerBin; sb < lowerBin; sb += 2) runningSum -= logAmpl[sb / 2];
+            for (int ab = prevUpperBin + 2; ab <= upperBin; ab += 2)
+                if (ab < fft_size) runningSum += logAmpl[ab / 2];
         } else {
             runningSum = 0.0f;
             for (int i = lowerBin; i <= upperBin && i / 2 < fft_size / 2; i += 2) runningSum += oldAmpl[i / 2];
@@ -356,6 +385,54 @@ void irb_shifteroo(float *buf, int n)                               // fp/ir.cpp
     std::memcpy(buf, t.data(), sizeof(float) * (size_t) n);
 }
 
+// averagingFilter with its element-wise phases on the GPU (log amplitude; exp / atan2 / cos / sin) and only
+// the order-sensitive float running sum on the host, on a spectrum that stays in device memory.  `passes`
+// repetitions (deconvolve uses 3).  Same operation order as irb_averaging_filter; the transcendental
+// functions are the device's, so results agree to rounding (1e-6), not bit for bit.
+static int smooth_on_device(irb_lfft *p, float *d_spec, int N, double octave_fraction, double sample_rate,
+                            int passes, int include_phase, int include_amplitude)
+{
+    const int nb = N / 2 + 1;                                       // bins 0..N/2; fft_size = 2N, reference "N" = N
+    const int fft_size = 2 * N;
+    const double fractPerSide = octave_fraction / 2.0;
+    const double freqPerBin = (sample_rate / 2) / (double) (N / 2);
+    const double up = std::pow(2.0, fractPerSide);
+    std::vector<int> lo((size_t) nb), hi((size_t) nb);              // window bounds in complex-bin units (:451-458)
+    for (int b = 0; b < nb; b++) {
+        const double binFreq = b * freqPerBin;
+        lo[b] = (int) std::round((binFreq / up) / freqPerBin);
+        hi[b] = (int) std::round((binFreq * up) / freqPerBin);
+    }
+    float tiny = 1e-16f;
+    const float logMin = std::log(tiny);                            // bins above Nyquist count as amplitude 0 -> 1e-16 (:497)
+    std::vector<float> logA((size_t) nb), avg((size_t) nb);
+    float *d_logA = reinterpret_cast<float *>(p->d_w0), *d_avg = reinterpret_cast<float *>(p->d_w1);   // work buffers are idle here
+    for (int pass = 0; pass < passes; pass++) {
+        irb::k_smooth_log_ampl<<<dim3((nb + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<const float2 *>(d_spec), d_logA, nb);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(logA.data(), d_logA, sizeof(float) * nb, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (log amplitudes)", hipGetErrorString(e));
+        float runningSum = 0.0f;                                    // :482-505, float, sequential
+        int prevLo = 0, prevHi = -1;
+        for (int b = 0; b < nb; b++) {
+            for (int sb = prevLo; sb < lo[b]; sb++) runningSum -= logA[sb];
+            for (int ab = prevHi + 1; ab <= hi[b]; ab++)
+                if (2 * ab < fft_size) runningSum += (ab < nb ? logA[ab] : logMin);
+            avg[b] = (float) (runningSum / ((double) (hi[b] - lo[b]) + 1.0));       // :519 (log domain; exp on device)
+            prevLo = lo[b];
+            prevHi = hi[b];
+        }
+        e = hipMemcpyAsync(d_avg, avg.data(), sizeof(float) * nb, hipMemcpyHostToDevice, p->stream);
+        if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (averages)", hipGetErrorString(e));
+        irb::k_smooth_apply<<<dim3((nb + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(d_spec), d_avg, nb, 1,
+                                                                                   include_phase, include_amplitude);
+        if ((e = hipGetLastError()) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "k_smooth_apply", hipGetErrorString(e));
+        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing", hipGetErrorString(e));
+    }
+    return IRB_OK;
+}
+
 // ---- convolution::deconvolve (fp/convolution.cpp:351-403) ---------------------------------------------
 int irb_deconvolve(int device, const float *num, int len_num, const float *den, int len_den, double sample_rate,
                    int smoothing, int include_phase, int include_amplitude, float *out, int out_len)
@@ -366,7 +443,7 @@ int irb_deconvolve(int device, const float *num, int len_num, const float *den, 
     if (N < 32) return irb_set_error_(IRB_ERR_ARG, "buffers shorter than 17 samples are not supported");
     if (out_len < N) return irb_set_error_(IRB_ERR_ARG, "out must hold nextPowerOfTwo(max(len)) samples");
     irb_lfft *p = nullptr;
-    int rc = irb_lfft_create(device, N, 2, &p);
+    int rc = cached_plan(device, N, 2, &p);
     if (rc != IRB_OK) return rc;
     do {
         hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * 2 * (size_t) N, p->stream);
@@ -379,17 +456,10 @@ int irb_deconvolve(int device, const float *num, int len_num, const float *den, 
         irb::k_cdiv<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
             reinterpret_cast<float2 *>(p->d_spec), reinterpret_cast<const float2 *>(p->d_spec + 2 * (size_t) N), nbins);
         if ((e = hipGetLastError()) != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "k_cdiv", hipGetErrorString(e)); break; }
-        if (smoothing) {                                            // :389-394: host (order-sensitive running sums)
-            std::vector<float> spec(2 * (size_t) N, 0.0f);
-            e = hipMemcpyAsync(spec.data(), p->d_spec, sizeof(float) * (N + 2), hipMemcpyDeviceToHost, p->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-            if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "spectrum download", hipGetErrorString(e)); break; }
+        if (smoothing) {                                            // :389-394: three passes of averagingFilter(1/13 octave)
             const float smoothPerAvg = 1.0 / 13.0;
-            for (int i = 0; i < 3; i++)
-                irb_averaging_filter(spec.data(), 2 * N, smoothPerAvg, sample_rate, 1, include_phase, include_amplitude);
-            e = hipMemcpyAsync(p->d_spec, spec.data(), sizeof(float) * (N + 2), hipMemcpyHostToDevice, p->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);       // spec goes out of scope
-            if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "spectrum upload", hipGetErrorString(e)); break; }
+            rc = smooth_on_device(p, p->d_spec, N, smoothPerAvg, sample_rate, 3, include_phase, include_amplitude);
+            if (rc != IRB_OK) break;
         }
         rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, 1);   // :397
         if (rc != IRB_OK) break;
@@ -398,7 +468,6 @@ int irb_deconvolve(int device, const float *num, int len_num, const float *den, 
         if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
         if (!include_phase) irb_shifteroo(out, N);                  // :400
     } while (0);
-    irb_lfft_destroy(p);
     return rc;
 }
 
@@ -431,7 +500,7 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
     const int ir_rows = (ir_ch == 2 && audio_ch == 2) ? 2 : 1;        // :296-304
     const int batch = audio_ch + ir_rows;
     irb_lfft *p = nullptr;
-    int rc = irb_lfft_create(device, N, batch, &p);
+    int rc = cached_plan(device, N, batch, &p);
     if (rc != IRB_OK) return rc;
     do {
         std::vector<float> host((size_t) batch * N, 0.0f);
@@ -460,7 +529,6 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
         if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
         for (int c = 0; c < audio_ch; c++) std::memcpy(out[c], &host[(size_t) c * N], sizeof(float) * (size_t) Lout);   // :340-344
     } while (0);
-    irb_lfft_destroy(p);
     return rc;
 }
 

@@ -175,6 +175,39 @@ __global__ __launch_bounds__(256) void k_cdiv(float2 *__restrict__ num, const fl
     num[i] = make_float2((a * c + b * d) / den2, (b * c - a * d) / den2);
 }
 
+// ---- averagingFilter, element-wise phases (reference fp/convolution.cpp:429-436 and :531-543) -------------
+// phase A: log of each bin's amplitude, amplitude first clamped to +-1e-16 (fp/tools.cpp:213-231)
+__global__ __launch_bounds__(256) void k_smooth_log_ampl(const float2 *__restrict__ spec, float *__restrict__ logA, int nbins)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    const double re = spec[i].x, im = spec[i].y;
+    float a = (float) sqrt(re * re + im * im);            // binAmpl: sqrt(pow(re,2) + pow(im,2)) in double
+    if (a < 1e-16f) a = 1e-16f;                           // amplitudes are never negative
+    logA[i] = logf(a);
+}
+
+// phase C: new amplitude exp(avg), old phase, back to (re, im); include flags as in the reference
+__global__ __launch_bounds__(256) void k_smooth_apply(float2 *__restrict__ spec, const float *__restrict__ avg, int nbins,
+                                                      int log_avg, int include_phase, int include_amplitude)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    float na = avg[i];
+    if (log_avg) na = expf(na);
+    if (!signbit(na) && na < 1e-16f) na = 1e-16f;         // roundTo1TenQuadrillionth
+    if (signbit(na) && na > -1e-16f) na = -1e-16f;
+    float re = spec[i].x, im = spec[i].y;
+    if (!signbit(re) && re < 1e-11f) re = 0.0f;           // roundToZero(.., 1e-11)
+    if (signbit(re) && re > -1e-11f) re = 0.0f;
+    if (!signbit(im) && im < 1e-11f) im = 0.0f;
+    if (signbit(im) && im > -1e-11f) im = 0.0f;
+    float phase = atan2f(im, re);
+    if (!include_amplitude) na = 1.0f;
+    if (!include_phase) phase = 0.0f;
+    spec[i] = make_float2(na * cosf(phase), na * sinf(phase));
+}
+
 // tools::complexMul over bins 0..N/2 (reference fp/convolution.cpp:326-331, fp/tools.cpp:44-52): a *= h
 __global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const float2 *__restrict__ h, int nbins)
 {

@@ -308,3 +308,26 @@ def test_paired_kernel_for_shared_ir_matches_unpaired(B, Lh):
         y = eng.process(x[:4])
         ref, _ = oracle.convolve_periodic(x[2:4], st, B)
         assert rel_rms(y[3], ref[1, :T * B]) < RMS_TOL
+
+
+def test_two_engines_in_two_threads():
+    """one caller thread per handle, several handles per process (ctypes drops the GIL during calls)"""
+    import threading
+    B, Lh, T = 256, 4096, 30
+    res = {}
+
+    def work(tag, seed):
+        x = _streams(2, 1, T * B, seed)
+        h = [decaying_ir(seed + 5 + i, Lh) for i in range(2)]
+        with FdlEngine(2, 1, B, Lh, max_blocks_per_call=4) as eng:
+            for i in range(2):
+                eng.set_ir(i, h[i])
+            y = np.concatenate([eng.process(x[:, j * B:(j + 3) * B]) for j in range(0, T, 3)], axis=1)
+        res[tag] = max(rel_rms(y[i], direct_f64(x[i:i + 1], h[i][None])[0, :T * B]) for i in range(2))
+
+    ts = [threading.Thread(target=work, args=(k, 100 * (k + 1))) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(res) == 4 and max(res.values()) < RMS_TOL
