@@ -60,8 +60,8 @@ int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_c
  * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows. */
 int  irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);
 
-/* The one-shot entry points above keep the calling thread's most recent FFT plan (device buffers, twiddle
- * tables, stream) for reuse; this releases it. */
+/* The one-shot entry points (here and irb_convolve_periodic) keep the calling thread's most recent FFT plan /
+ * engine (device buffers, twiddle tables, stream) for reuse; this releases them. */
 void irb_release_cached_plans(void);
 
 /* ---- reusable plan with device-resident buffers (bench, repeated transforms) ---- */

@@ -131,8 +131,11 @@ int cached_plan(int device, int N, int batch, irb_lfft **out)
 
 extern "C" {
 
+void irb_fdl_release_cached_engine_(void);     // fdl_engine.hip
+
 void irb_release_cached_plans(void)
 {
+    irb_fdl_release_cached_engine_();
     if (g_cache.plan) { irb_lfft_destroy(g_cache.plan); g_cache.plan = nullptr; }
 }
 

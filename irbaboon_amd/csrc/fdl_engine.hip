@@ -193,6 +193,8 @@ int upload_maps(irb_fdl *h)
 
 }  // namespace
 
+namespace { thread_local irb_fdl *g_offline_engine = nullptr; }   // irb_convolve_periodic's cached engine (no destructor: see deconv_engine.hip)
+
 extern "C" {
 
 const char *irb_last_error(void) { return g_err; }
@@ -545,12 +547,21 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     const long written = steps * B;
     if (!keep_reference_tail && Lout > written) steps += 1;   // flush the overlap the reference drops (:236-238)
 
-    irb_fdl_config cfg;
-    std::memset(&cfg, 0, sizeof cfg);
-    cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = Lh_eff;
-    cfg.max_blocks_per_call = (int) std::min<long>(steps, 4096);
-    irb_fdl *h = nullptr;
-    int rc = irb_fdl_create(&cfg, &h);
+    // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
+    // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
+    const int need_T = (int) std::min<long>(steps, 4096);
+    irb_fdl *h = g_offline_engine;
+    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= need_T && h->Tmax <= 8 * need_T + 64)) {
+        if (h) { irb_fdl_destroy(h); g_offline_engine = nullptr; }
+        irb_fdl_config cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = P * B;
+        cfg.max_blocks_per_call = need_T;
+        int rc0 = irb_fdl_create(&cfg, &h);
+        if (rc0 != IRB_OK) return rc0;
+        g_offline_engine = h;
+    }
+    int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
     rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
     if (rc == IRB_OK) {
@@ -564,11 +575,16 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 if (have > 0) std::memcpy(dst, audio[c] + s0, sizeof(float) * (size_t) have);
                 std::fill(dst + have, dst + n, 0.0f);
             }
-            hipError_t e = hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream);
+            hipError_t e = hipSuccess;
+            for (int c = 0; c < audio_ch && e == hipSuccess; c++)       // only the blocks of this call, per channel
+                e = hipMemcpyAsync(h->d_in + (size_t) c * stride, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) n,
+                                   hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
             rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
             if (rc != IRB_OK) break;
-            e = hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream);
+            for (int c = 0; c < audio_ch && e == hipSuccess; c++)
+                e = hipMemcpyAsync(h->h_io + (size_t) c * stride, h->d_out + (size_t) c * stride, sizeof(float) * (size_t) n,
+                                   hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
             const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;
@@ -577,8 +593,12 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 if (take > 0) std::memcpy(out[c] + s0, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) take);
         }
     }
-    irb_fdl_destroy(h);
     return rc;
+}
+
+void irb_fdl_release_cached_engine_(void)
+{
+    if (g_offline_engine) { irb_fdl_destroy(g_offline_engine); g_offline_engine = nullptr; }
 }
 
 }  // extern "C"
