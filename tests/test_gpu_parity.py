@@ -331,3 +331,43 @@ def test_two_engines_in_two_threads():
     for t in ts:
         t.join()
     assert len(res) == 4 and max(res.values()) < RMS_TOL
+
+
+def test_split_handoff_stress_under_load():
+    """The single-launch split path hands slabs between workgroups (release/acquire + ticket).  Hammer it:
+    many streams x splits, hundreds of steps, while another engine streams from HBM on a second HIP stream
+    (uneven load, warm caches).  A stale or missing slab is an O(1) error; the fused kernel is the reference."""
+    import threading
+    I, B, Lh, T = 48, 256, 24000, 240
+    x = _streams(I, 1, T * B, 4242)
+    irs = [decaying_ir(4300 + i, Lh) for i in range(I)]
+    stop = threading.Event()
+
+    def background():
+        with FdlEngine(256, 1, 256, 48000, flags=_lib.FORCE_FUSED) as bg:
+            for i in range(0, 256, 16):
+                bg.set_ir(i, decaying_ir(i, 48000))
+            d_in, d_out, stride = bg.device_io()
+            while not stop.is_set():
+                for _ in range(20):
+                    bg.process_device(d_in, d_out, stride, 1)
+                bg.synchronize()
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        outs = {}
+        for name, flags in (("fused", _lib.FORCE_FUSED), ("split", _lib.FORCE_SPLIT)):
+            with FdlEngine(I, 1, B, Lh, flags=flags) as eng:
+                for i in range(I):
+                    eng.set_ir(i, irs[i])
+                if name == "split":
+                    assert eng.info.splits >= 2
+                outs[name] = eng.process(x)
+    finally:
+        stop.set()
+        th.join()
+    for i in range(I):
+        assert rel_rms(outs["split"][i], outs["fused"][i]) < 2e-6
+    ref, _ = oracle.convolve_periodic(x[:1], irs[0][None], B)
+    assert rel_rms(outs["split"][0], ref[0, :T * B]) < RMS_TOL

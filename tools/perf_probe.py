@@ -57,6 +57,23 @@ def stereo(I=1024, B=256, Lh=96000, flags=0):
     print(f"stereo/mono-IR I={I} B={B} Lh={Lh} flags={flags}: {ms*1e3:.1f} us/step  {2*I*B/ms/1e3:.1f} Msamples/s")
 
 
+def rt(host_block=256, n=2000):
+    """processBlock-shaped adapter: wall time per host callback (stereo, 8 partitions, rolling IR refresh)"""
+    from irbaboon_amd import RtConvolver
+    r = RtConvolver(2, 256, 2048)
+    r.prepareToPlay(host_block)
+    buf = np.stack([white_noise(1, host_block), white_noise(2, host_block)])
+    for _ in range(50):
+        b = buf.copy(); r.processBlock(b)
+    ts = []
+    for _ in range(n):
+        b = buf.copy()
+        t0 = time.perf_counter(); r.processBlock(b); ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    print(f"rt adapter hostBlock={host_block}: median {np.median(ts):.1f} us, p99 {np.percentile(ts, 99):.1f} us, max {ts.max():.1f} us per callback "
+          f"(deadline {host_block/48000*1e6:.0f} us at 48 kHz)")
+
+
 def lfft(logn=20, batch=1, reps=50):
     """device-resident large real FFT: forward and inverse, and the full one-shot deconvolve vs the oracle"""
     import irbaboon_amd as ib
@@ -90,4 +107,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt}[mode](*args)
