@@ -37,8 +37,8 @@ def cpu_baseline(seconds):
     probe = white_noise(2000, LH)[None]
     t0 = time.perf_counter()
     oracle.convolve_periodic(probe, h, B)
-    rate = (probe.shape[1] + LH) / (time.perf_counter() - t0)       # samples/s incl. the P-block tail
-    La = int(max(4, min(400, seconds * rate / LH - 1))) * LH
+    per_step = (time.perf_counter() - t0) / (probe.shape[1] // B + LH // B)     # seconds per block step (audio + tail blocks)
+    La = int(max(4, min(400, (seconds / per_step - LH // B) * B / LH))) * LH
     x = white_noise(2001, La)[None]
     t0 = time.perf_counter()
     oracle.convolve_periodic(x, h, B)
