@@ -166,7 +166,9 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
     const int ntiles = (T + kTT - 1) / kTT;
     FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
-    FOR_N(h->N, irb::k_cmac_tiled<NN, kTT><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a));
+    // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
+    if (h->nt && ntiles == 1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    else { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
     h->ovl_cur ^= 1;

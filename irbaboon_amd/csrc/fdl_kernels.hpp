@@ -647,7 +647,7 @@ __device__ __forceinline__ void cmac2(float4 &acc, const float4 x, const float4 
     acc.w = fmaf(x.z, h.w, acc.w);  acc.w = fmaf(x.w, h.z, acc.w);
 }
 
-template <int N, int TT>
+template <int N, int TT, bool NT = false>
 __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
 {
     using G = MacGeom<N>;
@@ -680,14 +680,14 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
             float4 xr[2 * TT - 1];
 #pragma unroll
             for (int i = TT; i < 2 * TT - 1; i++)
-                xr[i] = X4[(size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col];
+                xr[i] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col);
             for (; k0 < se; k0 += TT) {
                 float4 h[TT];
 #pragma unroll
-                for (int u = 0; u < TT; u++) h[u] = H4[(size_t) (k0 + u) * G::L + col];
+                for (int u = 0; u < TT; u++) h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
 #pragma unroll
                 for (int i = 0; i < TT; i++)
-                    xr[i] = X4[(size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col];
+                    xr[i] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col);
 #pragma unroll
                 for (int u = 0; u < TT; u++) {
                     const float p = packed ? 0.0f : h[u].y;

@@ -1,0 +1,30 @@
+"""The committed bench line (profiles/r01_bench.json, copied from a real MI355X run) keeps the driver's
+contract: required keys, types, and internal consistency of the roofline / cpu_baseline objects."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_follows_contract():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "Msamples/s"
+    assert d["vs_baseline"] is None and base["published"] == {}            # nothing published to compare with
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # achieved = algorithmic bytes per launch / kernel duration; value = samples / step time
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    inst, blk = d["config"]["instances_per_gpu"], d["config"]["block"]
+    assert abs(d["value"] - inst * d["n_gpus"] * blk / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    per_stream = 8 * d["config"]["partitions"] * d["config"]["fft_len"] + 16 * blk
+    assert r["algorithmic_bytes_per_launch"] == inst * per_stream
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Msamples/s" and c["value"] > 0 and c["sample"]
