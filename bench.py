@@ -47,6 +47,28 @@ def cpu_baseline(seconds):
             "sample": f"1 mono stream, B={B}, Lh={LH}, La={La} samples ({La // B}+375 block steps), {dt:.1f} s"}
 
 
+def cpu_baseline_multicore(single, seconds):
+    """One independent stream per host core (the reference is single-threaded per stream): aggregate rate.
+    Threads suffice: each stream is one long C call and ctypes drops the GIL for its duration."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from irbaboon_amd.synth import decaying_ir, white_noise
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    La = int(max(2, min(100, seconds * single["value"] * 1e6 / LH))) * LH
+    data = [(white_noise(2000 + i, La)[None], decaying_ir(18000 + i, LH)[None]) for i in range(cores)]
+    oracle.lib()
+    ts = [threading.Thread(target=oracle.convolve_periodic, args=(x, h, B)) for x, h in data]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    wall = time.perf_counter() - t0
+    return {"value": round(cores * La / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} independent mono streams (one thread each), B={B}, Lh={LH}, La={La} each, {wall:.1f} s wall"}
+
+
 def _timed_calls(eng, d_in, d_out, stride, T, reps):
     eng.process_device(d_in, d_out, stride, T)
     eng.synchronize()
@@ -221,6 +243,7 @@ def main():
 
     if ranks.rank == 0 and ranks.world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        out["cpu_baseline_all_cores"] = cpu_baseline_multicore(out["cpu_baseline"], min(6.0, args.cpu_seconds))
     eng.close()
     ranks.close()
     if ranks.rank == 0:
