@@ -3,6 +3,7 @@
 // usage: test_host_mirror layout   -> error convention only (no GPU needed)
 //        test_host_mirror gpu      -> delta-at-100 IR must give a pure 100-sample delay
 #include "../../include/irb_fp_convolution.hpp"
+#include "../../include/irb_rt_adapter.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -43,5 +44,26 @@ int main(int argc, char **argv)
     for (int c = 0; c < 2; c++)
         for (int i = 0; i < 4096; i++) worst = std::fmax(worst, std::fabs(y.getReadPointer(c)[i + 100] - a.getReadPointer(c)[i]));
     std::printf("delta delay max err %.3g\n", worst);
-    return worst < 3e-6 ? 0 : 4;
+    if (!(worst < 3e-6)) return 4;
+
+    // processBlock-shaped adapter with the plug-in's constants: stereo, 256-sample blocks, 2048-sample IR ring,
+    // default IR = delta at 100 -> output = input delayed by 100 + one block (Source/PluginProcessor.cpp:46,169-174)
+    irb::RtConvolverT<PlanarBuffer> rt(0, 2, 256, 2048);
+    if (rt.prepareToPlay(256) != 256 || rt.partitions() != 8) return 5;
+    const int nblk = 24, H = 256;
+    PlanarBuffer in(2, nblk * H), outb(2, nblk * H);
+    for (auto &v : in.d) { s = s * 6364136223846793005ull + 1442695040888963407ull; v = (float) ((int64_t) (s >> 40) - (1 << 23)) / (float) (1 << 23); }
+    for (int b = 0; b < nblk; b++) {
+        PlanarBuffer blk(2, H);
+        for (int c = 0; c < 2; c++) std::memcpy(blk.getWritePointer(c), in.getReadPointer(c) + b * H, sizeof(float) * H);
+        rt.processBlock(blk);
+        for (int c = 0; c < 2; c++) std::memcpy(outb.getWritePointer(c) + b * H, blk.getReadPointer(c), sizeof(float) * H);
+    }
+    worst = 0;
+    const int d = 256 + 100;
+    for (int c = 0; c < 2; c++)
+        for (int i = d; i < nblk * H; i++) worst = std::fmax(worst, std::fabs(outb.getReadPointer(c)[i] - in.getReadPointer(c)[i - d]));
+    std::printf("rt delta delay max err %.3g\n", worst);
+    rt.releaseResources();
+    return worst < 3e-6 ? 0 : 6;
 }
