@@ -116,6 +116,15 @@ int  irb_fdl_reset(irb_fdl *h);
  * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.     */
 int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
 
+/* Same with one packed host buffer per direction: stream s, block j at in + s*stride + j*block (floats).
+ * No per-stream packing on the host; with buffers from irb_host_alloc (pinned) the transfers run at PCIe
+ * speed.  in == out is allowed.  Blocks until done.                                  */
+int  irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride, int n_blocks);
+
+/* Page-locked host memory for the packed API (hipHostMalloc / hipHostFree).          */
+void *irb_host_alloc(size_t bytes);
+void  irb_host_free(void *p);
+
 /* Same with device-resident audio: stream s, block j lives at
  * d_in + s*stride + j*block (floats); likewise d_out.  Asynchronous.            */
 int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks);

@@ -46,6 +46,9 @@ SYMBOLS = [
     ("irb_fdl_set_ir_spectra", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
     ("irb_fdl_reset", C.c_int, [C.c_void_p]),
     ("irb_fdl_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
+    ("irb_fdl_process_packed", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
+    ("irb_host_alloc", C.c_void_p, [C.c_size_t]),
+    ("irb_host_free", None, [C.c_void_p]),
     ("irb_fdl_process_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
     ("irb_fdl_synchronize", C.c_int, [C.c_void_p]),
     ("irb_fdl_mark", C.c_int, [C.c_void_p, C.c_int]),

@@ -482,6 +482,36 @@ int irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n
     return IRB_OK;
 }
 
+int irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride, int n_blocks)
+{
+    if (!h || !in || !out) return fail(IRB_ERR_ARG, "null argument");
+    if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
+    if (stride < (long) n_blocks * h->B) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
+    HIP_TRY(hipSetDevice(h->device));
+    const long dstride = (long) h->Tmax * h->B;
+    for (int done = 0; done < n_blocks; done += h->Tmax) {
+        const int nb = std::min(h->Tmax, n_blocks - done);
+        const size_t width = sizeof(float) * (size_t) nb * h->B;
+        HIP_TRY(hipMemcpy2DAsync(h->d_in, sizeof(float) * dstride, in + (size_t) done * h->B, sizeof(float) * stride, width, h->S,
+                                 hipMemcpyHostToDevice, h->stream));
+        int rc = irb_fdl_process_device(h, h->d_in, h->d_out, dstride, nb);
+        if (rc != IRB_OK) return rc;
+        HIP_TRY(hipMemcpy2DAsync(out + (size_t) done * h->B, sizeof(float) * stride, h->d_out, sizeof(float) * dstride, width, h->S,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return IRB_OK;
+}
+
+void *irb_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(IRB_ERR_HIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+void irb_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
 int irb_fdl_mark(irb_fdl *h, int slot)
 {
     if (!h || slot < 0 || slot > 1) return fail(IRB_ERR_ARG, "bad argument");

@@ -75,6 +75,14 @@ class FdlEngine:
         check(_lib.lib().irb_fdl_process(self._h, planar_ptrs(x), planar_ptrs(y), x.shape[1] // self.block))
         return y
 
+    def process_packed(self, x, out=None):
+        """x: one C-contiguous float32 array [streams][n_blocks*block]; no per-stream packing on the host.
+        Use pinned_empty() buffers for PCIe-speed transfers."""
+        assert x.dtype == np.float32 and x.flags.c_contiguous and x.shape[0] == self.streams and x.shape[1] % self.block == 0
+        y = np.empty_like(x) if out is None else out
+        check(_lib.lib().irb_fdl_process_packed(self._h, x.ctypes.data, y.ctypes.data, x.shape[1], x.shape[1] // self.block))
+        return y
+
     # ---- device-resident path (bench, smoke) ----
     def device_io(self):
         d_in, d_out, stride = C.c_void_p(), C.c_void_p(), C.c_long()
@@ -103,3 +111,28 @@ class FdlEngine:
         ms = C.c_float()
         check(_lib.lib().irb_fdl_elapsed_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+class _PinnedBlock:
+    """Owns one irb_host_alloc block and exposes it through the buffer protocol of a ctypes array; numpy arrays
+    built on it keep it alive through their .base chain."""
+
+    def __init__(self, n_floats):
+        self.ptr = _lib.lib().irb_host_alloc(max(n_floats, 1) * 4)
+        if not self.ptr:
+            raise _lib.IrbError(_lib.IRB_ERR_HIP, _lib.lib().irb_last_error().decode())
+        self.array = (C.c_float * max(n_floats, 1)).from_address(self.ptr)
+        self.array._owner = self                       # ctypes objects accept attributes: ties lifetimes together
+
+    def __del__(self):
+        try:
+            _lib.lib().irb_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape):
+    """float32 numpy array backed by page-locked host memory (irb_host_alloc) for the packed API."""
+    n = int(np.prod(shape))
+    block = _PinnedBlock(n)
+    return np.frombuffer(block.array, dtype=np.float32, count=n).reshape(shape)

@@ -371,3 +371,23 @@ def test_split_handoff_stress_under_load():
         assert rel_rms(outs["split"][i], outs["fused"][i]) < 2e-6
     ref, _ = oracle.convolve_periodic(x[:1], irs[0][None], B)
     assert rel_rms(outs["split"][0], ref[0, :T * B]) < RMS_TOL
+
+
+def test_packed_host_api_matches_pointer_api():
+    from irbaboon_amd.engine import pinned_empty
+    I, C, B, Lh, T = 3, 2, 128, 900, 11
+    x = _streams(I, C, T * B, 77)
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=4) as eng:
+        for i in range(I):
+            eng.set_ir(i, np.stack([decaying_ir(80 + 2 * i + c, Lh) for c in range(C)]))
+        ref = eng.process(x)
+        eng.reset()
+        assert np.array_equal(eng.process_packed(x), ref)
+        eng.reset()
+        xp, yp = pinned_empty(x.shape), pinned_empty(x.shape)
+        xp[:] = x
+        eng.process_packed(xp, yp)
+        assert np.array_equal(yp, ref)
+        eng.reset()
+        eng.process_packed(xp, xp)                       # in place
+        assert np.array_equal(xp, ref)

@@ -74,6 +74,40 @@ def rt(host_block=256, n=2000):
           f"(deadline {host_block/48000*1e6:.0f} us at 48 kHz)")
 
 
+def hostapi(I=2048, B=256, Lh=96000, T=1, reps=30):
+    """PCIe-inclusive rate through the host-pointer API (irb_fdl_process): pack, H2D, kernels, D2H, unpack"""
+    import ctypes as C
+    from irbaboon_amd._lib import lib, planar_ptrs, check
+    eng = FdlEngine(I, 1, B, Lh, max_blocks_per_call=T)
+    h0 = decaying_ir(1, Lh)
+    for i in range(I):
+        eng.set_ir(i, h0)
+    x = np.stack([white_noise(5 + s, T * B) for s in range(I)])
+    y = np.empty_like(x)
+    xp, yp = planar_ptrs(x), planar_ptrs(y)
+    check(lib().irb_fdl_process(eng._h, xp, yp, T))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        check(lib().irb_fdl_process(eng._h, xp, yp, T))
+    dt = (time.perf_counter() - t0) / reps
+    from irbaboon_amd.engine import pinned_empty
+    xp2, yp2 = pinned_empty(x.shape), pinned_empty(x.shape)
+    xp2[:] = x
+    eng.process_packed(xp2, yp2)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.process_packed(xp2, yp2)
+    dp = (time.perf_counter() - t0) / reps
+    eng.process_packed(x, y)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.process_packed(x, y)
+    dq = (time.perf_counter() - t0) / reps
+    print(f"   packed API: pinned {dp*1e3:.3f} ms ({I*T*B/dp/1e6:.1f} Msamples/s), pageable {dq*1e3:.3f} ms ({I*T*B/dq/1e6:.1f} Msamples/s)")
+    print(f"host API I={I} B={B} T={T}: {dt*1e3:.3f} ms per call  {I*T*B/dt/1e6:.1f} Msamples/s PCIe-inclusive "
+          f"({2*I*T*B*4/dt/1e9:.1f} GB/s over PCIe both ways)")
+
+
 def lfft(logn=20, batch=1, reps=50):
     """device-resident large real FFT: forward and inverse, and the full one-shot deconvolve vs the oracle"""
     import irbaboon_amd as ib
@@ -107,4 +141,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi}[mode](*args)
