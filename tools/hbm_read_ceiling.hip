@@ -23,6 +23,39 @@ __global__ __launch_bounds__(256) void k_read(const v4f *__restrict__ a, const v
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
 }
+// same two-region pattern, but fewer concurrent regions: TPB threads per workgroup, each workgroup walks
+// `per` streams one after the other
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_read_seq(const v4f *__restrict__ a, const v4f *__restrict__ b, float *out, int rows, int per)
+{
+    v4f acc = {0, 0, 0, 0};
+    for (int q = 0; q < per; q++) {
+        const size_t sidx = (size_t) blockIdx.x * per + q;
+        const v4f *pa = a + sidx * rows, *pb = b + sidx * rows;
+        for (int i = threadIdx.x; i + TPB < rows; i += 2 * TPB) {
+            v4f x0 = __builtin_nontemporal_load(pa + i), x1 = __builtin_nontemporal_load(pa + i + TPB);
+            v4f y0 = __builtin_nontemporal_load(pb + i), y1 = __builtin_nontemporal_load(pb + i + TPB);
+            acc += x0 * y0 + x1 * y1;
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+}
+// two regions, rows of 2 KB (128 float4): region a ascending, region b walked DESCENDING row by row (what the FDL
+// ring does: partition k pairs with slot head-k), 2 stripes of 128 lanes like k_step_fused<512>
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_read_rows(const v4f *__restrict__ a, const v4f *__restrict__ b, float *out, int nrows)
+{
+    const v4f *pa = a + (size_t) blockIdx.x * nrows * 128, *pb = b + (size_t) blockIdx.x * nrows * 128;
+    const int col = threadIdx.x & 127, stripe = threadIdx.x >> 7;
+    v4f acc = {0, 0, 0, 0};
+    for (int k = stripe; k + 2 < nrows; k += 4) {
+        const int s0 = BACKWARD ? nrows - 1 - k : k, s1 = BACKWARD ? nrows - 1 - (k + 2) : k + 2;
+        v4f x0 = __builtin_nontemporal_load(pa + (size_t) k * 128 + col), x1 = __builtin_nontemporal_load(pa + (size_t) (k + 2) * 128 + col);
+        v4f y0 = __builtin_nontemporal_load(pb + (size_t) s0 * 128 + col), y1 = __builtin_nontemporal_load(pb + (size_t) s1 * 128 + col);
+        acc += x0 * y0 + x1 * y1;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+}
 // linear grid-stride stream of the same bytes: the friendliest possible pattern
 template <bool NT>
 __global__ __launch_bounds__(256) void k_linear(const v4f *__restrict__ a, float *out, size_t n)
@@ -59,6 +92,33 @@ int main()
     run(k_read<true, 4>, "non-temporal, U=4");
     run(k_read<false, 4>, "default loads, U=4");
     run(k_read<true, 2>, "non-temporal, U=2");
+    auto runs = [&](auto kern, int tpb, int per, const char *name) {
+        const int grid = S / per;
+        for (int i = 0; i < 5; i++) kern<<<grid, tpb>>>(a, b, o, rows, per);
+        hipEventRecord(e0);
+        for (int i = 0; i < 50; i++) kern<<<grid, tpb>>>(a, b, o, rows, per);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-28s tpb %4d per %d: %.1f GB/s\n", name, tpb, per, 2.0 * n * 16 / (ms / 50 * 1e-3) / 1e9);
+    };
+    runs(k_read_seq<256>, 256, 1, "two regions nt");
+    runs(k_read_seq<256>, 256, 2, "two regions nt");
+    runs(k_read_seq<256>, 256, 4, "two regions nt");
+    runs(k_read_seq<512>, 512, 1, "two regions nt");
+    runs(k_read_seq<1024>, 1024, 1, "two regions nt");
+    runs(k_read_seq<512>, 512, 2, "two regions nt");
+    auto runr = [&](auto kern, const char *name) {
+        for (int i = 0; i < 5; i++) kern<<<S, 256>>>(a, b, o, 375);
+        hipEventRecord(e0);
+        for (int i = 0; i < 50; i++) kern<<<S, 256>>>(a, b, o, 375);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-28s %.1f GB/s\n", name, 2.0 * n * 16 / (ms / 50 * 1e-3) / 1e9);
+    };
+    runr(k_read_rows<false>, "rows: both ascending");
+    runr(k_read_rows<true>, "rows: b descending");
+    runr(k_read_rows<false>, "rows: both ascending");
+    runr(k_read_rows<true>, "rows: b descending");
     auto runl = [&](auto kern, int grid, const char *name) {
         for (int i = 0; i < 5; i++) kern<<<grid, 256>>>(a, o, n);
         hipEventRecord(e0);
