@@ -172,6 +172,9 @@ int  irb_rt_release_resources(irb_rt *p);
 int  irb_rt_set_ir(irb_rt *p, const float *ir, int len);
 /* buffer: planar host [channels][n], processed in place.                         */
 int  irb_rt_process_block(irb_rt *p, float *const *buffer, int n);
+/* Replaces processBlockBypassed (Source/PluginProcessor.cpp:584-590): host-only ring that keeps the plug-in's
+ * block delay while bypassed.  n must equal the prepared samples_per_block.            */
+int  irb_rt_process_block_bypassed(irb_rt *p, float *const *buffer, int n);
 int  irb_rt_latency(const irb_rt *p);
 int  irb_rt_partitions(const irb_rt *p);
 

@@ -48,6 +48,14 @@ public:
         if (irb_rt_process_block(rt, ptrs, buffer.getNumSamples()) != IRB_OK) { report(); buffer.clear(); }
     }
 
+    // processBlockBypassed (:584-590)
+    void processBlockBypassed(Buffer &buffer)
+    {
+        float *ptrs[16];
+        for (int c = 0; c < nch && c < 16; ++c) ptrs[c] = buffer.getWritePointer(c);
+        if (irb_rt_process_block_bypassed(rt, ptrs, buffer.getNumSamples()) != IRB_OK) report();
+    }
+
     int latency() const { return irb_rt_latency(rt); }
     int partitions() const { return irb_rt_partitions(rt); }
 

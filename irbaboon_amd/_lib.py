@@ -63,6 +63,7 @@ SYMBOLS = [
     ("irb_rt_release_resources", C.c_int, [C.c_void_p]),
     ("irb_rt_set_ir", C.c_int, [C.c_void_p, fp, C.c_int]),
     ("irb_rt_process_block", C.c_int, [C.c_void_p, fpp, C.c_int]),
+    ("irb_rt_process_block_bypassed", C.c_int, [C.c_void_p, fpp, C.c_int]),
     ("irb_rt_latency", C.c_int, [C.c_void_p]),
     ("irb_rt_partitions", C.c_int, [C.c_void_p]),
     # include/irb_deconv.h

@@ -34,6 +34,8 @@ struct irb_rt {
     std::vector<const float *> inp;           // per-channel pointers handed to the engine (sized at create)
     std::vector<float *> outp;
     int outSize = 0, outRd = 0, outWr = 0;
+    std::vector<float> bypassRing;            // [outSize][C][H] (:211)
+    int bypRd = 0, bypWr = 0;
     int inputBufferSampleIndex = 0, outputBufferSampleIndex = 0, outputSampleIndex = 0;
     int irWriteIndex = 0;                     // irFftBufferArray write index (:457-461)
 };
@@ -94,6 +96,8 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     p->outSize = next_pow2((int) std::ceil((float) p->B / (float) p->H) + 1);   // :205
     p->outRing.assign((size_t) p->outSize * p->C * p->H, 0.0f);                 // :210
     p->outRd = 1; p->outWr = 0;                                                 // :218
+    p->bypassRing.assign((size_t) p->outSize * p->C * p->H, 0.0f);              // :211
+    p->bypRd = 0; p->bypWr = 0;
     p->inputBufferSampleIndex = 0;                                              // :220
     p->outputBufferSampleIndex = 0;                                             // :221
     if (p->outputSampleIndex >= p->H) p->outputSampleIndex = 0;                 // reference: left as is (UB if too large)
@@ -120,6 +124,19 @@ int irb_rt_set_ir(irb_rt *p, const float *ir, int len)
         return irb_set_error_(IRB_ERR_ARG, msg);
     }
     p->ir.assign(ir, ir + len);
+    return IRB_OK;
+}
+
+int irb_rt_process_block_bypassed(irb_rt *p, float *const *buffer, int n)       // :584-590
+{
+    if (!p || !buffer) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (p->outSize == 0) return irb_set_error_(IRB_ERR_STATE, "process_block_bypassed before prepare_to_play");
+    if (n != p->H) return irb_set_error_(IRB_ERR_ARG, "bypassed blocks must have the prepared samples_per_block");
+    const size_t slot = (size_t) p->C * p->H;
+    for (int c = 0; c < p->C; c++) std::memcpy(p->bypassRing.data() + p->bypWr * slot + (size_t) c * p->H, buffer[c], sizeof(float) * n);   // :586
+    if (++p->bypWr >= p->outSize) p->bypWr = 0;                                  // :587
+    if (++p->bypRd >= p->outSize) p->bypRd = 0;                                  // :588
+    for (int c = 0; c < p->C; c++) std::memcpy(buffer[c], p->bypassRing.data() + p->bypRd * slot + (size_t) c * p->H, sizeof(float) * n);   // :589
     return IRB_OK;
 }
 

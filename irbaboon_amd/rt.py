@@ -36,6 +36,11 @@ class RtConvolver:
         assert buffer.dtype == np.float32 and buffer.flags.c_contiguous and buffer.shape[0] == self.channels
         check(_lib.lib().irb_rt_process_block(self._h, planar_ptrs(buffer), buffer.shape[1]))
 
+    def processBlockBypassed(self, buffer):
+        """Source/PluginProcessor.cpp:584-590: keeps the block delay while the plug-in is bypassed."""
+        assert buffer.dtype == np.float32 and buffer.flags.c_contiguous and buffer.shape[0] == self.channels
+        check(_lib.lib().irb_rt_process_block_bypassed(self._h, planar_ptrs(buffer), buffer.shape[1]))
+
     @property
     def latency(self):
         return _lib.lib().irb_rt_latency(self._h)

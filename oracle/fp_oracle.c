@@ -537,7 +537,7 @@ static void ring_clear(ring *r, int idx) { memset(ring_at(r, idx, 0), 0, sizeof(
 struct fp_rt {
     int C, B, N, fftBlockSize, P, H;
     int irRingLen;
-    ring input, audioFft, irFft, convResult, output;
+    ring input, audioFft, irFft, convResult, output, bypass;
     fp_fft *fft;
     float *inplace, *overlap;
     const float *ir; int irLen; float *irOwned;
@@ -571,7 +571,7 @@ void fp_rt_destroy(fp_rt *p)
 {
     if (!p) return;
     free(p->input.data); free(p->audioFft.data); free(p->irFft.data);
-    free(p->convResult.data); free(p->output.data);
+    free(p->convResult.data); free(p->output.data); free(p->bypass.data);
     fp_fft_destroy(p->fft); free(p->inplace); free(p->overlap); free(p->irOwned); free(p);
 }
 
@@ -588,6 +588,7 @@ void fp_rt_prepareToPlay(fp_rt *p, int samplesPerBlock)
     ring_init(&p->input, inputArraySize, p->C, p->fftBlockSize);          /* :208 */
     ring_init(&p->convResult, inputArraySize, p->C, p->fftBlockSize);     /* :209 */
     ring_init(&p->output, outputArraySize, p->C, p->H);                   /* :210 */
+    ring_init(&p->bypass, outputArraySize, p->C, p->H);                   /* :211 */
     p->output.rd = 1;                                                     /* :218 */
     p->inputBufferSampleIndex = 0;                                        /* :220 */
     p->outputBufferSampleIndex = 0;                                       /* :221 */
@@ -699,4 +700,16 @@ void fp_rt_processBlock(fp_rt *p, float *const *buffer, int n)
             p->outputSampleIndex = 0;
         }
     }
+}
+
+/* processBlockBypassed, Source/PluginProcessor.cpp:584-590 */
+void fp_rt_processBlockBypassed(fp_rt *p, float *const *buffer, int n)
+{
+    if (n != p->H) return;                       /* makeCopyOf would resize the slot; only the prepared size is restated */
+    for (int c = 0; c < p->C; c++)
+        memcpy(ring_at(&p->bypass, p->bypass.wr, c), buffer[c], sizeof(float) * (size_t) n);      /* :586 */
+    ring_incr_wr(&p->bypass);                                                                     /* :587 */
+    ring_incr_rd(&p->bypass);                                                                     /* :588 */
+    for (int c = 0; c < p->C; c++)
+        memcpy(buffer[c], ring_at(&p->bypass, p->bypass.rd, c), sizeof(float) * (size_t) n);      /* :589 */
 }

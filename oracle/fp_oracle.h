@@ -90,6 +90,9 @@ void   fp_rt_prepareToPlay(fp_rt *p, int samplesPerBlock);
 void   fp_rt_set_ir(fp_rt *p, const float *ir, int len);
 /* in-place on planar buffer[channels][n]; convolution part only (no gain/limiter). */
 void   fp_rt_processBlock(fp_rt *p, float *const *buffer, int n);
+/* processBlockBypassed (Source/PluginProcessor.cpp:584-590): the bypass ring keeps the plug-in's block delay.
+ * n must equal the prepared host block size. */
+void   fp_rt_processBlockBypassed(fp_rt *p, float *const *buffer, int n);
 int    fp_rt_latency(const fp_rt *p);
 int    fp_rt_partitions(const fp_rt *p);
 

@@ -36,6 +36,7 @@ def _load():
     lib.fp_rt_prepareToPlay.argtypes = [C.c_void_p, C.c_int]
     lib.fp_rt_set_ir.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.fp_rt_processBlock.argtypes = [C.c_void_p, _fpp, C.c_int]
+    lib.fp_rt_processBlockBypassed.argtypes = [C.c_void_p, _fpp, C.c_int]
     lib.fp_rt_latency.restype = C.c_int
     lib.fp_rt_latency.argtypes = [C.c_void_p]
     lib.fp_rt_partitions.restype = C.c_int
@@ -123,6 +124,11 @@ class RtProcessor:
         assert buf.dtype == np.float32 and buf.flags.c_contiguous and buf.shape[0] == self.channels
         ptrs = (C.POINTER(C.c_float) * buf.shape[0])(*[buf[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(buf.shape[0])])
         lib().fp_rt_processBlock(self.p, ptrs, buf.shape[1])
+
+    def process_block_bypassed(self, buf):
+        assert buf.dtype == np.float32 and buf.flags.c_contiguous and buf.shape[0] == self.channels
+        ptrs = (C.POINTER(C.c_float) * buf.shape[0])(*[buf[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(buf.shape[0])])
+        lib().fp_rt_processBlockBypassed(self.p, ptrs, buf.shape[1])
 
     @property
     def latency(self):

@@ -391,3 +391,25 @@ def test_packed_host_api_matches_pointer_api():
         eng.reset()
         eng.process_packed(xp, xp)                       # in place
         assert np.array_equal(xp, ref)
+
+
+@pytest.mark.parametrize("host_block", [64, 128, 256, 512])
+def test_rt_bypass_delay_line_matches_oracle(host_block):
+    """processBlockBypassed (Source/PluginProcessor.cpp:584-590): host-only delay ring, bit exact."""
+    ref, gpu = oracle.RtProcessor(2, 256, 2048), RtConvolver(2, 256, 2048)
+    ref.prepare_to_play(host_block)
+    gpu.prepareToPlay(host_block)
+    x = np.stack([white_noise(61, host_block * 12), white_noise(62, host_block * 12)])
+    yr, yg = np.empty_like(x), np.empty_like(x)
+    for i in range(0, x.shape[1], host_block):
+        a = np.ascontiguousarray(x[:, i:i + host_block]); b = a.copy()
+        ref.process_block_bypassed(a); gpu.processBlockBypassed(b)
+        yr[:, i:i + host_block], yg[:, i:i + host_block] = a, b
+    assert np.array_equal(yr, yg)
+    ring = 1
+    while ring < int(np.ceil(256 / host_block)) + 1:
+        ring *= 2
+    d = (ring - 1) * host_block                       # delay = ring-1 host blocks (:205,:587-589)
+    assert np.array_equal(yg[:, d:], x[:, :-d]) and not yg[:, :d].any()
+    with pytest.raises(_lib.IrbError):
+        gpu.processBlockBypassed(np.zeros((2, host_block + 1), np.float32))
