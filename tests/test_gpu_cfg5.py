@@ -186,3 +186,44 @@ def test_ir_spectra_roundtrip_through_engine():
         assert np.array_equal(b.process(x), ya)
         raw = ib.IRtoRealFFTRaw(irs[0], B)
         assert np.allclose(raw[:P], sp[0], atol=1e-6)
+
+
+def test_end_to_end_measurement_chain():
+    """The plug-in's whole data path on the GPU, product APIs only: play the sweep through two 'rooms'
+    (convolvePeriodic), extract both IRs (deconvolve, Source/PluginProcessor.cpp:306-312), derive the
+    compensation filter (createIRFilt = deconvolve(target, base), :606-615) and run it through the
+    processBlock-shaped convolver.  Checked against float64 maths in the band the sweep excites."""
+    sr, Nsw = 48000, 65536
+    sweep = exp_sine_sweep(49152, sr, 20.0, sr / 2, fade_from=(11.0 / 12.0) * sr / 2, n_total=Nsw)
+    room_t, room_b = decaying_ir(1, 600), decaying_ir(2, 400)
+    room_b[0] += 1.5                                     # base room well conditioned (it is divided by)
+    cap_t = ib.convolvePeriodic(sweep[None], room_t[None], 256)[0, :Nsw]
+    cap_b = ib.convolvePeriodic(sweep[None], room_b[None], 256)[0, :Nsw]
+    ir_t = ib.deconvolve(cap_t, sweep, sr, smoothing=False)
+    ir_b = ib.deconvolve(cap_b, sweep, sr, smoothing=False)
+    band = slice(int(60 / sr * Nsw), int(18000 / sr * Nsw))
+
+    def band_err(got, want_time):
+        G = np.fft.rfft(got.astype(np.float64))
+        W = np.fft.rfft(np.pad(want_time.astype(np.float64), (0, Nsw - want_time.size)))
+        return np.sqrt(np.mean(np.abs(G[band] - W[band]) ** 2) / np.mean(np.abs(W[band]) ** 2))
+
+    assert band_err(ir_t, room_t) < 2e-3 and band_err(ir_b, room_b) < 2e-3
+    filt = ib.deconvolve(ir_t, ir_b, sr, smoothing=False)                  # createIRFilt without smoothing
+    H = np.fft.rfft(np.pad(room_t.astype(np.float64), (0, Nsw - 600))) / np.fft.rfft(np.pad(room_b.astype(np.float64), (0, Nsw - 400)))
+    F = np.fft.rfft(filt.astype(np.float64))
+    assert np.sqrt(np.mean(np.abs(F[band] - H[band]) ** 2) / np.mean(np.abs(H[band]) ** 2)) < 5e-3
+    # the real-time convolver uses the first 2048 samples of the filter (irPartitions fixed at 8, :225)
+    rt = ib.RtConvolver(2, 256, 2048)
+    rt.prepareToPlay(256)
+    rt.setIR(filt)
+    n = 256 * 40
+    x = np.stack([white_noise(7, n), white_noise(8, n)])
+    y = np.empty_like(x)
+    for i in range(0, n, 256):
+        blk = np.ascontiguousarray(x[:, i:i + 256])
+        rt.processBlock(blk)
+        y[:, i:i + 256] = blk
+    want = np.stack([np.convolve(x[c].astype(np.float64), filt[:2048].astype(np.float64))[:n] for c in range(2)])
+    s = 10 * 256
+    assert rel_rms(y[:, 256 + s:], want[:, s:n - 256]) < 1e-5
