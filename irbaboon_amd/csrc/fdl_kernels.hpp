@@ -657,7 +657,10 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
     const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
     const int set = a.set_of_stream[s];
     const int np = a.np_of_set[set];
-    const int col0 = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
+    // the stripe index is the same for a whole wave (LW >= 64 for every supported N >= 256; smaller N are not
+    // worth tuning): telling the compiler so keeps partition indices and ring slots in scalar registers
+    const int col0 = threadIdx.x % G::LW;
+    const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
     const int q = split * G::STRIPES + stripe;
     // whole groups of TT partitions per worker (worker = one stripe of one split).  The H rows between
     // np and the next multiple of TT are kept at zero by the host, so there is no remainder loop.
