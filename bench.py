@@ -148,8 +148,9 @@ def main():
     from irbaboon_amd.synth import decaying_ir, white_noise
 
     ranks = shard.Ranks()
-    if ranks.world != args.gpus and ranks.world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}")
+    if ranks.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: for N > 1 launch one rank per GPU with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     dev = ranks.local_rank % torch.cuda.device_count()
