@@ -156,6 +156,22 @@ int  irb_convolve_periodic(int device,
                            int processBlockSize, int keep_reference_tail,
                            float *const *out);
 
+/* ---- several GPUs from one host process ------------------------------------------------------------------
+ * Instances never communicate, so a group of handles shards them by contiguous ranges: device d of D owns
+ * instances [d*I/D, (d+1)*I/D) (balanced to within one).  No peer access, no collective.  irb_fdl_multi_process
+ * enqueues pack/H2D/kernels/D2H on every device's stream from the calling thread and only then waits, so the
+ * devices run concurrently.  `devices` may name a device more than once (tests on a one-GPU box do). */
+typedef struct irb_fdl_multi irb_fdl_multi;
+int  irb_fdl_multi_create(const irb_fdl_config *cfg /* n_instances = total over all devices; .device, .stream ignored */,
+                          const int *devices, int n_devices, irb_fdl_multi **out);
+void irb_fdl_multi_destroy(irb_fdl_multi *m);
+/* which shard owns `instance`, and its index there */
+int  irb_fdl_multi_owner(const irb_fdl_multi *m, int instance, int *shard, int *local_instance);
+int  irb_fdl_multi_set_ir(irb_fdl_multi *m, int instance, const float *const *ir, int ir_channels, int len);
+int  irb_fdl_multi_reset(irb_fdl_multi *m);
+/* in/out: one host pointer per GLOBAL stream (instance*channels + ch), n_blocks*block samples each */
+int  irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const *out, int n_blocks);
+
 /* ---- processBlock-shaped adapter ---------------------------------------------
  * Replaces the IRCAP_IDLE branch of IRBaboonAudioProcessor::processBlock
  * (Source/PluginProcessor.cpp:408-562) with its set-up in the ctor (:57-82) and

@@ -56,6 +56,12 @@ SYMBOLS = [
     ("irb_fdl_device_io", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
     ("irb_fdl_upload", C.c_int, [C.c_void_p, C.c_void_p, fp, C.c_size_t]),
     ("irb_fdl_download", C.c_int, [C.c_void_p, fp, C.c_void_p, C.c_size_t]),
+    ("irb_fdl_multi_create", C.c_int, [C.POINTER(FdlConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("irb_fdl_multi_destroy", None, [C.c_void_p]),
+    ("irb_fdl_multi_owner", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("irb_fdl_multi_set_ir", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
+    ("irb_fdl_multi_reset", C.c_int, [C.c_void_p]),
+    ("irb_fdl_multi_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
     ("irb_convolve_periodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, C.c_int, C.c_int, fpp]),
     ("irb_rt_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_rt_destroy", None, [C.c_void_p]),

@@ -461,23 +461,41 @@ int irb_fdl_synchronize(irb_fdl *h)
     return IRB_OK;
 }
 
+// one chunk (nb <= Tmax blocks starting at block `done`) of the host-pointer call, split so that several handles
+// can be driven concurrently from one thread: begin = pack + H2D + kernels + D2H (all enqueued), end = wait + unpack
+static int process_chunk_begin(irb_fdl *h, const float *const *in, int done, int nb)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    const long stride = (long) h->Tmax * h->B;
+    const size_t n = (size_t) nb * h->B;
+    for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
+    HIP_TRY(hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
+    int rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
+    if (rc != IRB_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
+    return IRB_OK;
+}
+
+static int process_chunk_end(irb_fdl *h, float *const *out, int done, int nb)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const long stride = (long) h->Tmax * h->B;
+    const size_t n = (size_t) nb * h->B;
+    for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, h->h_io + (size_t) s * stride, sizeof(float) * n);
+    return IRB_OK;
+}
+
 int irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks)
 {
     if (!h || !in || !out) return fail(IRB_ERR_ARG, "null argument");
     if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
     for (int s = 0; s < h->S; s++) if (!in[s] || !out[s]) return fail(IRB_ERR_ARG, "in/out[%d] is null", s);
-    HIP_TRY(hipSetDevice(h->device));
-    const long stride = (long) h->Tmax * h->B;
     for (int done = 0; done < n_blocks; done += h->Tmax) {
         const int nb = std::min(h->Tmax, n_blocks - done);
-        const size_t n = (size_t) nb * h->B;
-        for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
-        HIP_TRY(hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
-        int rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
+        int rc = process_chunk_begin(h, in, done, nb);
+        if (rc == IRB_OK) rc = process_chunk_end(h, out, done, nb);
         if (rc != IRB_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, h->h_io + (size_t) s * stride, sizeof(float) * n);
     }
     return IRB_OK;
 }
@@ -626,6 +644,91 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         }
     }
     return rc;
+}
+
+// ---- several GPUs from one host process ------------------------------------------------------------------
+struct irb_fdl_multi {
+    std::vector<irb_fdl *> shard;
+    std::vector<int> first;           // first[d] = first global instance of shard d; first[D] = total
+    int C = 0, Tmax = 1;
+};
+
+void irb_fdl_multi_destroy(irb_fdl_multi *m)
+{
+    if (!m) return;
+    for (irb_fdl *h : m->shard) irb_fdl_destroy(h);
+    delete m;
+}
+
+int irb_fdl_multi_create(const irb_fdl_config *cfg, const int *devices, int n_devices, irb_fdl_multi **out)
+{
+    if (!cfg || !devices || !out) return fail(IRB_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (n_devices < 1 || cfg->n_instances < n_devices) return fail(IRB_ERR_ARG, "need 1 <= n_devices <= n_instances");
+    irb_fdl_multi *m = new (std::nothrow) irb_fdl_multi;
+    if (!m) return fail(IRB_ERR_ARG, "out of host memory");
+    m->C = cfg->channels; m->Tmax = cfg->max_blocks_per_call;
+    const int base = cfg->n_instances / n_devices, extra = cfg->n_instances % n_devices;
+    int lo = 0;
+    for (int d = 0; d < n_devices; d++) {
+        irb_fdl_config c = *cfg;
+        c.device = devices[d]; c.stream = nullptr; c.n_instances = base + (d < extra ? 1 : 0);
+        irb_fdl *h = nullptr;
+        int rc = irb_fdl_create(&c, &h);
+        if (rc != IRB_OK) { irb_fdl_multi_destroy(m); return rc; }
+        m->shard.push_back(h);
+        m->first.push_back(lo);
+        lo += c.n_instances;
+    }
+    m->first.push_back(lo);
+    *out = m;
+    return IRB_OK;
+}
+
+int irb_fdl_multi_owner(const irb_fdl_multi *m, int instance, int *shard, int *local_instance)
+{
+    if (!m) return fail(IRB_ERR_ARG, "null handle");
+    if (instance < 0 || instance >= m->first.back()) return fail(IRB_ERR_ARG, "instance %d out of range", instance);
+    int d = 0;
+    while (instance >= m->first[d + 1]) d++;
+    if (shard) *shard = d;
+    if (local_instance) *local_instance = instance - m->first[d];
+    return IRB_OK;
+}
+
+int irb_fdl_multi_set_ir(irb_fdl_multi *m, int instance, const float *const *ir, int ir_channels, int len)
+{
+    int d = 0, li = 0;
+    int rc = irb_fdl_multi_owner(m, instance, &d, &li);
+    if (rc != IRB_OK) return rc;
+    return irb_fdl_set_ir(m->shard[d], li, ir, ir_channels, len);
+}
+
+int irb_fdl_multi_reset(irb_fdl_multi *m)
+{
+    if (!m) return fail(IRB_ERR_ARG, "null handle");
+    for (irb_fdl *h : m->shard) { int rc = irb_fdl_reset(h); if (rc != IRB_OK) return rc; }
+    return IRB_OK;
+}
+
+int irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const *out, int n_blocks)
+{
+    if (!m || !in || !out) return fail(IRB_ERR_ARG, "null argument");
+    if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
+    const int D = (int) m->shard.size();
+    for (int s = 0; s < m->first.back() * m->C; s++) if (!in[s] || !out[s]) return fail(IRB_ERR_ARG, "in/out[%d] is null", s);
+    for (int done = 0; done < n_blocks; done += m->Tmax) {
+        const int nb = std::min(m->Tmax, n_blocks - done);
+        for (int d = 0; d < D; d++) {                  // enqueue on every device first ...
+            int rc = process_chunk_begin(m->shard[d], in + (size_t) m->first[d] * m->C, done, nb);
+            if (rc != IRB_OK) return rc;
+        }
+        for (int d = 0; d < D; d++) {                  // ... then collect
+            int rc = process_chunk_end(m->shard[d], out + (size_t) m->first[d] * m->C, done, nb);
+            if (rc != IRB_OK) return rc;
+        }
+    }
+    return IRB_OK;
 }
 
 void irb_fdl_release_cached_engine_(void)

@@ -113,6 +113,43 @@ class FdlEngine:
         return ms.value
 
 
+class MultiGpuEngine:
+    """Instances sharded by contiguous ranges over several devices of ONE process (irb_fdl_multi_*)."""
+
+    def __init__(self, n_instances, channels, block, max_ir_len, devices, max_blocks_per_call=1, flags=0):
+        self._h = C.c_void_p()
+        cfg = FdlConfig(0, n_instances, channels, block, max_ir_len, max_blocks_per_call, None, flags)
+        dev = (C.c_int * len(devices))(*devices)
+        check(_lib.lib().irb_fdl_multi_create(C.byref(cfg), dev, len(devices), C.byref(self._h)))
+        self.streams, self.block = n_instances * channels, block
+
+    def close(self):
+        if self._h:
+            _lib.lib().irb_fdl_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def owner(self, instance):
+        d, li = C.c_int(), C.c_int()
+        check(_lib.lib().irb_fdl_multi_owner(self._h, instance, C.byref(d), C.byref(li)))
+        return d.value, li.value
+
+    def set_ir(self, instance, ir):
+        ir = np.ascontiguousarray(np.atleast_2d(ir), np.float32)
+        check(_lib.lib().irb_fdl_multi_set_ir(self._h, instance, planar_ptrs(ir), ir.shape[0], ir.shape[1]))
+
+    def reset(self):
+        check(_lib.lib().irb_fdl_multi_reset(self._h))
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.streams and x.shape[1] % self.block == 0
+        y = np.empty_like(x)
+        check(_lib.lib().irb_fdl_multi_process(self._h, planar_ptrs(x), planar_ptrs(y), x.shape[1] // self.block))
+        return y
+
+
 class _PinnedBlock:
     """Owns one irb_host_alloc block and exposes it through the buffer protocol of a ctypes array; numpy arrays
     built on it keep it alive through their .base chain."""

@@ -413,3 +413,27 @@ def test_rt_bypass_delay_line_matches_oracle(host_block):
     assert np.array_equal(yg[:, d:], x[:, :-d]) and not yg[:, :d].any()
     with pytest.raises(_lib.IrbError):
         gpu.processBlockBypassed(np.zeros((2, host_block + 1), np.float32))
+
+
+def test_multi_device_group_matches_single_engine():
+    """irb_fdl_multi_*: instances sharded over several handles of one process (here three shards on device 0,
+    the only one a test box has); outputs must equal a single engine's, and the ranges must match shard.py."""
+    from irbaboon_amd.engine import MultiGpuEngine
+    from irbaboon_amd import shard
+    I, C, B, Lh, T = 7, 2, 128, 1500, 9
+    x = _streams(I, C, T * B, 1234)
+    irs = [np.stack([decaying_ir(1300 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=4) as one:
+        for i in range(I):
+            one.set_ir(i, irs[i])
+        ref = one.process(x)
+    m = MultiGpuEngine(I, C, B, Lh, devices=[0, 0, 0], max_blocks_per_call=4)
+    for i in range(I):
+        m.set_ir(i, irs[i])
+        d, li = m.owner(i)
+        lo, hi = shard.instance_range(I, d, 3)
+        assert lo <= i < hi and li == i - lo
+    assert np.array_equal(m.process(x), ref)
+    m.reset()
+    assert np.array_equal(m.process(x), ref)
+    m.close()
