@@ -328,6 +328,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
         return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
     for (int c = 0; c < ir_channels; c++) if (!ir[c] && len > 0) return fail(IRB_ERR_ARG, "ir[%d] is null", c);
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));       // the pinned IR staging may still feed an earlier partition refresh
     const int np = (len + h->B - 1) / h->B;
     const int nrows = (ir_channels == 2 && h->C == 2) ? 2 : 1;        // fp/convolution.cpp:94-101
     const size_t row = (size_t) np * h->B;

@@ -74,9 +74,12 @@ class LargeFft:
         self.d_time, self.d_spec = t.value, s.value
 
     def close(self):
-        if self._h:
-            _lib.lib().irb_lfft_destroy(self._h)
-            self._h = C.c_void_p()
+        try:
+            if self._h:
+                _lib.lib().irb_lfft_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
 
     __del__ = close
 

@@ -28,9 +28,12 @@ class FdlEngine:
         self.info = info
 
     def close(self):
-        if self._h:
-            _lib.lib().irb_fdl_destroy(self._h)
-            self._h = C.c_void_p()
+        try:
+            if self._h:
+                _lib.lib().irb_fdl_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:          # interpreter shutdown: the module may already be torn down
+            pass
 
     __del__ = close
 
@@ -124,9 +127,12 @@ class MultiGpuEngine:
         self.streams, self.block = n_instances * channels, block
 
     def close(self):
-        if self._h:
-            _lib.lib().irb_fdl_multi_destroy(self._h)
-            self._h = C.c_void_p()
+        try:
+            if self._h:
+                _lib.lib().irb_fdl_multi_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
 
     __del__ = close
 

@@ -15,9 +15,12 @@ class RtConvolver:
         self.channels = channels
 
     def close(self):
-        if self._h:
-            _lib.lib().irb_rt_destroy(self._h)
-            self._h = C.c_void_p()
+        try:
+            if self._h:
+                _lib.lib().irb_rt_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
 
     __del__ = close
 
