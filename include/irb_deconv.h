@@ -60,6 +60,19 @@ int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_c
  * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows. */
 int  irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);
 
+/* ---- fp::ExpSineSweep, HOST code (the sweep generator stays on the host: one-off O(N) work) --------------
+ * Replaces: ExpSineSweep::generate / generateInv / getSampleIndexAtFreq / getFreqAtSampleIndex / linFadeout
+ * (fp/ExpSineSweep.cpp:26-41, 59-79, 101-146, 147-164, 212-260).  Samples are double like the reference's
+ * AudioBuffer<double>; `generate` writes (int)(sampleRate*durationSecs) samples (out_len must hold them) and
+ * returns that count, or a negative error code.  linFadeout takes the start index (getSampleIndexAtFreq). */
+int    irb_sweep_generate(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
+                          double *out, int out_len);
+int    irb_sweep_generate_inv(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
+                              double *out, int out_len);
+int    irb_sweep_sample_index_at_freq(double freq, double duration_secs, double sample_rate, double low_freq, double high_freq);
+double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sample_rate, double low_freq, double high_freq);
+int    irb_sweep_lin_fadeout(double *sweep, int n, int index);
+
 /* The one-shot entry points (here and irb_convolve_periodic) keep the calling thread's most recent FFT plan /
  * engine (device buffers, twiddle tables, stream) for reuse; this releases them. */
 void irb_release_cached_plans(void);

@@ -7,3 +7,4 @@ from .engine import FdlEngine                       # noqa: F401
 from .rt import RtConvolver                         # noqa: F401
 from .deconvolution import (LargeFft, averagingFilter, deconvolve, fftInvTransform,   # noqa: F401,E402
                             fftTransform, invertFilter, nextPowerOfTwo, shifteroo)
+from .sweep import ExpSineSweep   # noqa: F401,E402

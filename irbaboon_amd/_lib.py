@@ -82,6 +82,11 @@ SYMBOLS = [
     ("irb_invert_filter", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int]),
     ("irb_convolve_nonperiodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, fpp]),
     ("irb_ir_to_real_fft_raw", C.c_int, [C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]),
+    ("irb_sweep_generate", C.c_int, [C.c_double] * 5 + [C.POINTER(C.c_double), C.c_int]),
+    ("irb_sweep_generate_inv", C.c_int, [C.c_double] * 5 + [C.POINTER(C.c_double), C.c_int]),
+    ("irb_sweep_sample_index_at_freq", C.c_int, [C.c_double] * 5),
+    ("irb_sweep_freq_at_sample_index", C.c_double, [C.c_int] + [C.c_double] * 4),
+    ("irb_sweep_lin_fadeout", C.c_int, [C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("irb_release_cached_plans", None, []),
     ("irb_lfft_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_lfft_destroy", None, [C.c_void_p]),

@@ -483,6 +483,79 @@ int irb_invert_filter(int device, const float *ir, int len, int sample_rate, flo
     return irb_deconvolve(device, pulse.data(), len, ir, len, (double) sample_rate, 1, 1, 1, out, out_len);
 }
 
+// ---- fp::ExpSineSweep (host) ---------------------------------------------------------------------------
+namespace {
+struct SweepPar { double SR, w1, w2, T, K, L; };
+SweepPar sweep_par(double durationSecs, double sampleRate, double lowFreq, double highFreq)   // fp/ExpSineSweep.cpp:212-220
+{
+    SweepPar p;
+    p.SR = sampleRate;
+    p.T = p.SR * durationSecs;
+    p.w1 = lowFreq / p.SR * 2 * M_PI;
+    p.w2 = highFreq / p.SR * 2 * M_PI;
+    p.K = p.T * p.w1 / std::log(p.w2 / p.w1);
+    p.L = p.T / std::log(p.w2 / p.w1);
+    return p;
+}
+bool sweep_args_ok(double d, double sr, double lo, double hi) { return d > 0 && sr > 0 && lo > 0 && hi > lo; }
+}  // namespace
+
+int irb_sweep_generate(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
+                       double *out, int out_len)                                                // :26-41
+{
+    if (!out || !sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq)) return irb_set_error_(IRB_ERR_ARG, "bad sweep parameters");
+    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
+    const int n = (int) p.T;
+    if (out_len < n) return irb_set_error_(IRB_ERR_ARG, "out too small for the sweep");
+    const double gain = std::pow(10.0, dB_gain / 20.0);                                          // tools::dBToLin
+    for (int i = 0; i < n; i++) out[i] = gain * std::sin(p.K * (std::exp((double) i / p.L) - 1.0));
+    return n;
+}
+
+int irb_sweep_generate_inv(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
+                           double *out, int out_len)                                            // :59-79
+{
+    const int n = irb_sweep_generate(duration_secs, sample_rate, low_freq, high_freq, dB_gain, out, out_len);
+    if (n < 0) return n;
+    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
+    std::reverse(out, out + n);
+    const double k = std::pow(10.0, (-6.0 * std::log2(p.w2 / p.w1)) / 20.0 / p.T);             // -6 dB/oct
+    double kIterator = k;
+    for (int i = 0; i < n; i++) { out[i] *= kIterator; kIterator *= k; }
+    return n;
+}
+
+int irb_sweep_sample_index_at_freq(double freq, double duration_secs, double sample_rate, double low_freq, double high_freq)   // :243-258
+{
+    if (!sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq) || !(freq > 0)) return -1;
+    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
+    const double lf = (p.w1 * p.SR / (2 * M_PI));
+    const double oct = std::log(freq / lf) / std::log(2);
+    const double totalOct = std::log(p.w2 / p.w1) / std::log(2);
+    const int t_rounded = (int) std::round(oct / totalOct * p.T);
+    if (t_rounded < 0 || t_rounded >= p.T) return -1;                                            // "out of bounds for this sweep"
+    return t_rounded;
+}
+
+double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sample_rate, double low_freq, double high_freq)   // :225-240
+{
+    if (!sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq)) return -1;
+    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
+    if (index < 0 || index >= (int) p.T) return -1;
+    const double lf = p.w1 * p.SR / (2 * M_PI);
+    const double totalOct = std::log(p.w2 / p.w1) / std::log(2);
+    return lf * std::pow(2.0, (double) index / p.T * totalOct);
+}
+
+int irb_sweep_lin_fadeout(double *sweep, int n, int index)                                      // :147-164
+{
+    if (!sweep || n < 0) return irb_set_error_(IRB_ERR_ARG, "bad argument");
+    if (n == 0 || index < 0 || index >= n) return IRB_OK;                                         // nothing to fade
+    const int fadeoutSampleLength = n - index;
+    for (int i = index; i < n; i++) sweep[i] = sweep[i] * (fadeoutSampleLength - (i - index)) / fadeoutSampleLength;
+    return IRB_OK;
+}
+
 // ---- convolution::convolveNonPeriodic (fp/convolution.cpp:246-347) ------------------------------------
 int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch, int La,
                              const float *const *ir, int ir_ch, int Lh, float *const *out)

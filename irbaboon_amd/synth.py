@@ -59,7 +59,7 @@ def exp_sine_sweep(n_sweep, sample_rate, f_lo=20.0, f_hi=None, fade_from=None, n
     s = np.sin(K * (np.exp(i / L) - 1.0))
     if fade_from is not None:
         wf = fade_from / sample_rate * 2 * np.pi
-        idx = int(L * np.log(wf / w1))                     # sample index where the sweep reaches fade_from
+        idx = int(round(L * np.log(wf / w1)))              # getSampleIndexAtFreq (fp/ExpSineSweep.cpp:243-258)
         idx = min(max(idx, 0), n_sweep - 1)
         n = n_sweep - idx
         s[idx:] *= (n - np.arange(n)) / n

@@ -8,6 +8,8 @@
  */
 #include "fp_oracle.h"
 
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -507,6 +509,79 @@ int fp_invertFilter(const float *ir, int len, int sampleRate, float *out)
     int N = fp_deconvolve(pulse, len, ir, len, (double) sampleRate, 1, 1, 1, out);
     free(pulse);
     return N;
+}
+
+/* ------------------------------------------------------------------------- */
+/* fp::ExpSineSweep                                                            */
+/* ------------------------------------------------------------------------- */
+typedef struct { double SR, w1, w2, T, K, L; } sweep_par;
+
+/* fp/ExpSineSweep.cpp:212-220 */
+static sweep_par sweep_params(double durationSecs, double sampleRate, double lowFreq, double highFreq)
+{
+    sweep_par p;
+    p.SR = sampleRate;
+    p.T = p.SR * durationSecs;
+    p.w1 = lowFreq / p.SR * 2 * M_PI;
+    p.w2 = highFreq / p.SR * 2 * M_PI;
+    p.K = p.T * p.w1 / log(p.w2 / p.w1);
+    p.L = p.T / log(p.w2 / p.w1);
+    return p;
+}
+
+/* fp/ExpSineSweep.cpp:26-41, gain via tools::dBToLin (fp/tools.cpp:94-96) */
+int fp_sweep_generate(double durationSecs, double sampleRate, double lowFreq, double highFreq, double dBGain, double *out)
+{
+    const sweep_par p = sweep_params(durationSecs, sampleRate, lowFreq, highFreq);
+    const int n = (int) p.T;
+    const double gain = pow(10.0, dBGain / 20.0);
+    for (int i = 0; i < n; i++) out[i] = gain * sin(p.K * (exp((double) i / p.L) - 1.0));
+    return n;
+}
+
+/* fp/ExpSineSweep.cpp:59-79: reversed sweep with -6 dB/oct envelope */
+int fp_sweep_generateInv(double durationSecs, double sampleRate, double lowFreq, double highFreq, double dBGain, double *out)
+{
+    const sweep_par p = sweep_params(durationSecs, sampleRate, lowFreq, highFreq);
+    const int n = fp_sweep_generate(durationSecs, sampleRate, lowFreq, highFreq, dBGain, out);
+    for (int i = 0; i < n / 2; i++) { double t = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = t; }
+    const double k = pow(10.0, (-6.0 * log2(p.w2 / p.w1)) / 20.0 / p.T);
+    double kIterator = k;
+    for (int i = 0; i < n; i++) { out[i] *= kIterator; kIterator *= k; }
+    return n;
+}
+
+/* fp/ExpSineSweep.cpp:243-258 */
+int fp_sweep_getSampleIndexAtFreq(double freq, double durationSecs, double sampleRate, double lowFreq, double highFreq)
+{
+    const sweep_par p = sweep_params(durationSecs, sampleRate, lowFreq, highFreq);
+    double lf = (p.w1 * p.SR / (2 * M_PI));
+    double oct = log(freq / lf) / log(2);
+    double totalOct = log(p.w2 / p.w1) / log(2);
+    double t = oct / totalOct * p.T;
+    int t_rounded = (int) round(t);
+    if (t_rounded < 0 || t_rounded >= p.T) return -1;
+    return t_rounded;
+}
+
+/* fp/ExpSineSweep.cpp:225-240 */
+double fp_sweep_getFreqAtSampleIndex(int index, double durationSecs, double sampleRate, double lowFreq, double highFreq)
+{
+    const sweep_par p = sweep_params(durationSecs, sampleRate, lowFreq, highFreq);
+    if (index < 0 || index >= (int) p.T) return -1;
+    double lf = p.w1 * p.SR / (2 * M_PI);
+    double totalOct = log(p.w2 / p.w1) / log(2);
+    double oct = (double) index / p.T * totalOct;
+    return lf * pow(2.0, oct);
+}
+
+/* fp/ExpSineSweep.cpp:147-164, index = getSampleIndexAtFreq(freq) */
+void fp_sweep_linFadeout(double *sweep, int n, int index)
+{
+    if (n == 0 || index < 0) return;
+    int fadeoutSampleLength = n - index;
+    for (int i = index; i < n; i++)
+        sweep[i] = sweep[i] * (fadeoutSampleLength - (i - index)) / fadeoutSampleLength;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -76,6 +76,14 @@ int  fp_deconvolve(const float *num, int len_num, const float *den, int len_den,
 void fp_shifteroo(float *buf, int n);
 int  fp_invertFilter(const float *ir, int len, int sampleRate, float *out);
 
+/* ---- fp::ExpSineSweep (fp/ExpSineSweep.cpp:26-41, 59-79, 101-164, 212-260): the sweep that feeds config 5.
+ *      All in double, as the reference.  generate writes (int)(SR*durationSecs) samples and returns that count. ---- */
+int    fp_sweep_generate(double durationSecs, double sampleRate, double lowFreq, double highFreq, double dBGain, double *out);
+int    fp_sweep_generateInv(double durationSecs, double sampleRate, double lowFreq, double highFreq, double dBGain, double *out);
+int    fp_sweep_getSampleIndexAtFreq(double freq, double durationSecs, double sampleRate, double lowFreq, double highFreq);
+double fp_sweep_getFreqAtSampleIndex(int index, double durationSecs, double sampleRate, double lowFreq, double highFreq);
+void   fp_sweep_linFadeout(double *sweep, int n, int index);
+
 /* ---- IRBaboonAudioProcessor convolution state (Source/PluginProcessor.cpp
  *      ctor :57-82, prepareToPlay :164-234, processBlock IDLE branch :408-562,
  *      rings per fp/CircularBufferArray.cpp:94-128) ----

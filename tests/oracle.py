@@ -215,3 +215,37 @@ def invert_filter(ir, sample_rate):
     out = np.zeros(next_pow2(ir.size), np.float32)
     _bind_cfg5().fp_invertFilter(_f(ir), ir.size, int(sample_rate), _f(out))
     return out
+
+
+# ---- fp::ExpSineSweep (fp/ExpSineSweep.cpp) ----
+def sweep_generate(duration, sr, lo, hi, gain_db=0.0, inverse=False):
+    l = lib()
+    dp = C.POINTER(C.c_double)
+    for f in (l.fp_sweep_generate, l.fp_sweep_generateInv):
+        f.restype = C.c_int
+        f.argtypes = [C.c_double] * 5 + [dp]
+    out = np.zeros(int(sr * duration) + 1, np.float64)
+    n = (l.fp_sweep_generateInv if inverse else l.fp_sweep_generate)(duration, sr, lo, hi, gain_db, out.ctypes.data_as(dp))
+    return out[:n].copy()
+
+
+def sweep_index_at_freq(freq, duration, sr, lo, hi):
+    l = lib()
+    l.fp_sweep_getSampleIndexAtFreq.restype = C.c_int
+    l.fp_sweep_getSampleIndexAtFreq.argtypes = [C.c_double] * 5
+    return l.fp_sweep_getSampleIndexAtFreq(freq, duration, sr, lo, hi)
+
+
+def sweep_freq_at_index(index, duration, sr, lo, hi):
+    l = lib()
+    l.fp_sweep_getFreqAtSampleIndex.restype = C.c_double
+    l.fp_sweep_getFreqAtSampleIndex.argtypes = [C.c_int] + [C.c_double] * 4
+    return l.fp_sweep_getFreqAtSampleIndex(index, duration, sr, lo, hi)
+
+
+def sweep_lin_fadeout(sweep, index):
+    l = lib()
+    l.fp_sweep_linFadeout.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int]
+    s = np.ascontiguousarray(sweep, np.float64).copy()
+    l.fp_sweep_linFadeout(s.ctypes.data_as(C.POINTER(C.c_double)), s.size, index)
+    return s
