@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -48,6 +49,7 @@ std::vector<float2> root_table(int root, int count, int stride)      // W_root^(
 
 struct irb_lfft {
     int device = 0, N = 0, M = 0, M1 = 0, M2 = 0, max_batch = 1, logE = 0;
+    int tile_rows = 0;                           // four-step passes: rows/columns per workgroup (0 = one wave per item)
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tabA = nullptr, *d_tabB = nullptr;
@@ -74,20 +76,45 @@ irb::LfftArgs args_of(const irb_lfft *p, int batch)
 {
     irb::LfftArgs a;
     a.tw1 = p->d_tw1; a.tw2 = p->d_tw2; a.tabA = p->d_tabA; a.tabB = p->d_tabB; a.logE = p->logE;
-    a.N = p->N; a.M = p->M; a.M1 = p->M1; a.M2 = p->M2; a.batch = batch;
+    a.N = p->N; a.M = p->M; a.M1 = p->M1; a.M2 = p->M2; a.batch = batch; a.scale = 1.0f;
     return a;
+}
+
+// one tiled pass; R is fixed per plan (8 or 16 rows per workgroup; LDS = R*(MX+1)*8 + MX*8 bytes, up to 144 KiB)
+template <int MX, bool INV, bool COLS>
+int launch_tile(irb_lfft *p, const irb::LfftArgs &a, const float2 *src, float2 *dst, int nwg)
+{
+    const int R = p->tile_rows;
+    const size_t lds = sizeof(float2) * ((size_t) R * (MX + 1) + MX);
+    if (R == 16 && MX <= 1024) {
+        auto k = irb::k_lfft_tile<MX, 16, INV, COLS>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        k<<<dim3(nwg), dim3(irb::kWave * 16), lds, p->stream>>>(a, src, dst);
+    } else if (R == 8) {
+        auto k = irb::k_lfft_tile<MX, 8, INV, COLS>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        k<<<dim3(nwg), dim3(irb::kWave * 8), lds, p->stream>>>(a, src, dst);
+    } else {
+        return irb_set_error_(IRB_ERR_ARG, "unsupported tile height");
+    }
+    return IRB_OK;
 }
 
 // complex M-point transform of `batch` items: src -> dst (dst may equal neither work buffer's alias of src)
 template <bool INV>
 int complex_fft(irb_lfft *p, const float2 *src, float2 *tmp, float2 *dst, int batch)
 {
-    const irb::LfftArgs a = args_of(p, batch);
+    irb::LfftArgs a = args_of(p, batch);
+    if (INV) a.scale = 1.0f / (float) p->N;             // the last pass of an inverse transform applies 1/N
     if (p->M2 == 1) {
         FOR_M(p->M1, {
             constexpr int NF = irb::WaveGeom<MM>::NF;
             irb::k_lfft_small<MM, INV><<<dim3((batch + NF - 1) / NF), dim3(irb::kWave * NF), 0, p->stream>>>(a, src, dst);
         });
+    } else if (p->tile_rows > 0) {
+        // tiled passes (coalesced global traffic through LDS); R waves per workgroup
+        FOR_M(p->M1, { int rc = launch_tile<MM, INV, true>(p, a, src, tmp, batch * (p->M2 / p->tile_rows)); if (rc != IRB_OK) return rc; });
+        FOR_M(p->M2, { int rc = launch_tile<MM, INV, false>(p, a, tmp, dst, batch * (p->M1 / p->tile_rows)); if (rc != IRB_OK) return rc; });
     } else {
         FOR_M(p->M1, {
             constexpr int NF = irb::WaveGeom<MM>::NF;
@@ -177,6 +204,11 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
     if (p->M <= 2048) { p->M1 = p->M; p->M2 = 1; }
     else { p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1; }
     p->logE = std::min(10, ilog2(p->N));
+    if (p->M2 > 1) {
+        p->tile_rows = 8;                            // 16 leaves too few workgroups at 2^20 (tools/perf_probe.py lfft)
+        if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 8, 16
+        if (p->tile_rows == 16 && std::max(p->M1, p->M2) > 1024) p->tile_rows = 8;
+    }
     const int E = 1 << p->logE;
     int rc = IRB_OK;
     do {
@@ -230,11 +262,9 @@ int irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int 
     const long work = (long) batch * (p->M / 2 + 1);
     irb::k_rsplit_inv<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(args_of(p, batch), d_spec, p->d_w0);
     HIP_TRY(hipGetLastError());
-    float2 *dst = (p->M2 == 1) ? p->d_w1 : p->d_w0;          // four-step: w0 -> w1 -> w0 ; small: w0 -> w1
-    int rc = complex_fft<true>(p, p->d_w0, p->d_w1, dst, batch);
+    // the last pass writes the N real samples (as M interleaved pairs), already scaled, straight to d_out
+    int rc = complex_fft<true>(p, p->d_w0, p->d_w1, reinterpret_cast<float2 *>(d_out), batch);
     if (rc != IRB_OK) return rc;
-    const long n = (long) batch * p->N;
-    irb::k_scale_real<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, p->stream>>>(reinterpret_cast<const float *>(dst), d_out, n, 1.0f / (float) p->N);
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }

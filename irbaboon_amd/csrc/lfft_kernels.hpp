@@ -23,6 +23,7 @@ struct LfftArgs {
     const float2 *tabA, *tabB;    // W_N^(i*E), i < N/E ; W_N^i, i < E
     int           logE;           // E = 1 << logE
     int           N, M, M1, M2, batch;
+    float         scale;          // applied by the last pass of an inverse transform (1/N), 1 otherwise
 };
 
 __device__ __forceinline__ float2 big_twiddle(const LfftArgs &a, unsigned e)    // W_N^e, e < N
@@ -81,7 +82,67 @@ __global__ __launch_bounds__(kWave * WaveGeom<M2>::NF) void k_lfft_rows(LfftArgs
     if (!live) return;
     wave_fft<M2, INV>(l_buf[wave], l_tw, lane);
     float2 *dst = out + b * a.M + k1;
-    for (int k2 = lane; k2 < M2; k2 += kWave) dst[(size_t) k2 * a.M1] = l_buf[wave][k2];
+    for (int k2 = lane; k2 < M2; k2 += kWave) {
+        const float2 v = l_buf[wave][k2];
+        dst[(size_t) k2 * a.M1] = make_float2(v.x * a.scale, v.y * a.scale);
+    }
+}
+
+// ---- tiled passes: R adjacent columns (pass 1) / rows (pass 2) per workgroup, one wave each, with the global
+// traffic staged through a padded LDS tile so that every global access is an R*8-byte contiguous piece
+// (the one-wave-per-item kernels above touch 8 bytes per 4-KiB stride in one of their two phases).
+// Dynamic LDS: R*(MX+1) + MX float2.
+template <int MX, int R, bool INV, bool COLS>
+__global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char l_raw[];
+    constexpr int LD = MX + 1;                               // padded row: transposed accesses spread over banks
+    constexpr int NT = kWave * R;
+    float2 *tile = reinterpret_cast<float2 *>(l_raw);        // [R][LD]
+    float2 *l_tw = tile + R * LD;                            // [MX]
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int other = COLS ? a.M2 : a.M1;                    // length of the dimension the groups run along
+    const int groups = other / R;
+    const int g = blockIdx.x % groups;
+    const long b = blockIdx.x / groups;
+    const int i0 = g * R;                                    // first column n2 (COLS) / first row k1 (rows)
+    const float2 *src = in + b * a.M;
+    float2 *dst = out + b * a.M;
+    for (int i = threadIdx.x; i < MX; i += NT) l_tw[i] = COLS ? a.tw1[i] : a.tw2[i];
+    if (COLS) {
+        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // x[n1*M2 + n2]: R contiguous n2 per n1
+            const int n1 = idx / R, r = idx % R;
+            tile[r * LD + n1] = src[(size_t) n1 * a.M2 + i0 + r];
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // T[k1*M2 + n2]: whole rows
+            const int r = idx / MX, n2 = idx % MX;
+            tile[r * LD + n2] = src[(size_t) (i0 + r) * MX + n2];
+        }
+    }
+    __syncthreads();
+    float2 *mine = tile + wave * LD;
+    wave_fft<MX, INV>(mine, l_tw, lane);
+    if (COLS) {
+        const unsigned n2 = (unsigned) (i0 + wave);
+        for (int k1 = lane; k1 < MX; k1 += kWave) {
+            const float2 w = big_twiddle(a, 2u * n2 * (unsigned) k1);    // W_M^(n2*k1)
+            mine[k1] = INV ? cmulc(mine[k1], w) : cmul(mine[k1], w);
+        }
+    }
+    __syncthreads();
+    if (COLS) {
+        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // T[k1*M2 + n2]
+            const int k1 = idx / R, r = idx % R;
+            dst[(size_t) k1 * a.M2 + i0 + r] = tile[r * LD + k1];
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // Z[k1 + M1*k2]: R contiguous k1 per k2
+            const int k2 = idx / R, r = idx % R;
+            const float2 v = tile[r * LD + k2];
+            dst[(size_t) k2 * a.M1 + i0 + r] = make_float2(v.x * a.scale, v.y * a.scale);
+        }
+    }
 }
 
 // ---- M <= 2048: the whole complex transform in one wave ----------------------------------------------
@@ -100,7 +161,10 @@ __global__ __launch_bounds__(kWave * WaveGeom<M>::NF) void k_lfft_small(LfftArgs
     __syncthreads();
     if (!live) return;
     wave_fft<M, INV>(l_buf[wave], l_tw, lane);
-    for (int n = lane; n < M; n += kWave) out[b * M + n] = l_buf[wave][n];
+    for (int n = lane; n < M; n += kWave) {
+        const float2 v = l_buf[wave][n];
+        out[b * M + n] = make_float2(v.x * a.scale, v.y * a.scale);
+    }
 }
 
 // ---- real <-> complex split passes (element-wise over bin pairs b, M-b) ---------------------------------
