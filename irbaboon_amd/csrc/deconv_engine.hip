@@ -80,23 +80,33 @@ irb::LfftArgs args_of(const irb_lfft *p, int batch)
     return a;
 }
 
-// one tiled pass; R is fixed per plan (8 or 16 rows per workgroup; LDS = R*(MX+1)*8 + MX*8 bytes, up to 144 KiB)
-template <int MX, bool INV, bool COLS>
+// one tiled pass; R is fixed per plan (8 or 16 rows per workgroup; LDS = R*(MX+1)*8 + MX*8 bytes, up to 144 KiB).
+// SETUP = true only raises the kernel's dynamic-LDS limit (done once per plan, at create).
+template <int MX, bool INV, bool COLS, bool SETUP = false>
 int launch_tile(irb_lfft *p, const irb::LfftArgs &a, const float2 *src, float2 *dst, int nwg)
 {
     const int R = p->tile_rows;
     const size_t lds = sizeof(float2) * ((size_t) R * (MX + 1) + MX);
     if (R == 16 && MX <= 1024) {
         auto k = irb::k_lfft_tile<MX, 16, INV, COLS>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        k<<<dim3(nwg), dim3(irb::kWave * 16), lds, p->stream>>>(a, src, dst);
+        if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
+        else k<<<dim3(nwg), dim3(irb::kWave * 16), lds, p->stream>>>(a, src, dst);
     } else if (R == 8) {
         auto k = irb::k_lfft_tile<MX, 8, INV, COLS>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        k<<<dim3(nwg), dim3(irb::kWave * 8), lds, p->stream>>>(a, src, dst);
+        if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
+        else k<<<dim3(nwg), dim3(irb::kWave * 8), lds, p->stream>>>(a, src, dst);
     } else {
         return irb_set_error_(IRB_ERR_ARG, "unsupported tile height");
     }
+    return IRB_OK;
+}
+
+int setup_tiles(irb_lfft *p)
+{
+    if (p->tile_rows <= 0) return IRB_OK;
+    const irb::LfftArgs a = {};
+    FOR_M(p->M1, { int rc = launch_tile<MM, false, true, true>(p, a, nullptr, nullptr, 0); if (rc == IRB_OK) rc = launch_tile<MM, true, true, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
+    FOR_M(p->M2, { int rc = launch_tile<MM, false, false, true>(p, a, nullptr, nullptr, 0); if (rc == IRB_OK) rc = launch_tile<MM, true, false, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
     return IRB_OK;
 }
 
@@ -233,6 +243,7 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
             (e = hipMemcpy(p->d_tabB, tB.data(), sizeof(float2) * tB.size(), hipMemcpyHostToDevice)) != hipSuccess) {
             rc = failf(IRB_ERR_HIP, "%s: %s", "plan allocation", hipGetErrorString(e)); break;
         }
+        rc = setup_tiles(p);
     } while (0);
     if (rc != IRB_OK) { irb_lfft_destroy(p); return rc; }
     *out = p;
