@@ -78,6 +78,8 @@ int  irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out);
 /* Replaces: releaseResources / dtor (Source/PluginProcessor.cpp:240-248, 89-96). */
 void irb_fdl_destroy(irb_fdl *h);
 
+/* Geometry the handle derived (N, P, ring length ...).  No reference counterpart: the reference keeps these as
+ * locals (fp/convolution.cpp:45-52) / members (Source/PluginProcessor.h:194-198).    */
 int  irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info);
 
 /* Replaces: IR partitioning + forward FFT (fp/convolution.cpp:106-125) including
@@ -129,10 +131,12 @@ void  irb_host_free(void *p);
  * d_in + s*stride + j*block (floats); likewise d_out.  Asynchronous.            */
 int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks);
 
+/* Wait for everything enqueued on the handle's stream (no reference counterpart: the reference is synchronous). */
 int  irb_fdl_synchronize(irb_fdl *h);
 
 /* Stream-ordered timing on the handle's stream (hipEvent): `mark` records event
- * slot 0 or 1; `elapsed_ms` waits for both and returns slot1 - slot0.            */
+ * slot 0 or 1; `elapsed_ms` waits for both and returns slot1 - slot0.  Measurement
+ * support for bench.py; no reference counterpart (the reference has no timing code). */
 int  irb_fdl_mark(irb_fdl *h, int slot);
 int  irb_fdl_elapsed_ms(irb_fdl *h, float *ms);
 
