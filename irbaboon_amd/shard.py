@@ -51,7 +51,10 @@ class Ranks:
 
     def barrier(self):
         if self._dist is not None:
-            self._dist.barrier()
+            if self.backend == "nccl":
+                self._dist.barrier(device_ids=[self.local_rank])
+            else:
+                self._dist.barrier()
 
     def max(self, value):
         if self._dist is None:
