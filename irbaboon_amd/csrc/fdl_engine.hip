@@ -51,6 +51,7 @@ struct irb_fdl {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
+    bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
@@ -163,11 +164,17 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     a.splits = tiled_splits(h, T);
     a.nq = a.splits * stripes;
     a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
+    // one complex bin per lane, 16 outputs per tile: fewer bytes per FMA.  Pays when the rows come from HBM (working
+    // set beyond the Infinity Cache) and the call is long enough; cache-resident calls are faster with k_cmac_tiled
+    const bool one_bin = h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
+    const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
+    if (one_bin) a.nq = a.splits * stripes1;
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
-    const int ntiles = (T + kTT - 1) / kTT;
+    const int ntiles = one_bin ? (T + 15) / 16 : (T + kTT - 1) / kTT;
     FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
+    if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
-    if (h->nt && ntiles == 1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    else if (h->nt && ntiles == 1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     else { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
@@ -246,6 +253,8 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
     if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
+    h->tiled1 = h->nt;
+    if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };

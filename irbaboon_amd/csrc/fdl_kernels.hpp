@@ -685,12 +685,14 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
             for (int i = TT; i < 2 * TT - 1; i++)
                 xr[i] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col);
             for (; k0 < se; k0 += TT) {
+                // issue order = order of first use (partition u needs h[u] and, as its only NEW row, xr[TT-1-u]):
+                // loads complete in order, so the products of partition 0 can start after two loads instead of 16
                 float4 h[TT];
 #pragma unroll
-                for (int u = 0; u < TT; u++) h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
-#pragma unroll
-                for (int i = 0; i < TT; i++)
-                    xr[i] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col);
+                for (int u = 0; u < TT; u++) {
+                    h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
+                    xr[TT - 1 - u] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - u, a.R) * G::L + col);
+                }
 #pragma unroll
                 for (int u = 0; u < TT; u++) {
                     const float p = packed ? 0.0f : h[u].y;
@@ -713,6 +715,66 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
 }
 
 // one wave: sum the nq partial rows of one output block into buf (LDS)
+// Variant with ONE complex bin per lane and TT = 16 outputs per tile: half the bytes per FMA of k_cmac_tiled
+// (per 16 partitions: 32 eight-byte loads feed 256 complex MACs), at the price of 8-byte loads and ~140 VGPRs.
+template <int N, int TT>
+__global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
+{
+    constexpr int M = N / 2;
+    constexpr int LW = M < kThreads ? M : kThreads;          // lanes across a row
+    constexpr int CPT = M / LW, STRIPES = kThreads / LW;
+    const int ntiles = (a.T + TT - 1) / TT;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
+    const int set = a.set_of_stream[s];
+    const int np = a.np_of_set[set];
+    const int col0 = threadIdx.x % LW;
+    const int stripe = LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / LW) : (int) (threadIdx.x / LW);
+    const int q = split * STRIPES + stripe;
+    const int nG = (np + 7) / 8, nW = a.splits * STRIPES;      // H rows are zero-padded to multiples of 8
+    const int sb = (int) ((long) nG * q / nW) * 8, se = (int) ((long) nG * (q + 1) / nW) * 8;
+    const float2 *H2 = a.H + (size_t) set * a.P * M;
+    const float2 *X2 = a.X + (size_t) s * a.R * M;
+#pragma unroll 1
+    for (int c = 0; c < CPT; c++) {
+        const int col = col0 + c * LW;
+        const bool packed = (col == 0);
+        float2 acc[TT];
+#pragma unroll
+        for (int j = 0; j < TT; j++) acc[j] = make_float2(0.f, 0.f);
+        int k0 = sb;
+        if (k0 < se) {
+            float2 xr[TT + 7];                                 // window for 8 partitions x TT outputs
+#pragma unroll
+            for (int i = 8; i < TT + 7; i++) xr[i] = X2[(size_t) ring_slot(a.head, j0 - k0 - 7 + i, a.R) * M + col];
+            for (; k0 < se; k0 += 8) {
+                float2 h[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    h[u] = H2[(size_t) (k0 + u) * M + col];
+                    xr[7 - u] = X2[(size_t) ring_slot(a.head, j0 - k0 - u, a.R) * M + col];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float p = packed ? 0.0f : h[u].y;
+                    const float qq = packed ? h[u].y : h[u].x;
+#pragma unroll
+                    for (int j = 0; j < TT; j++) {
+                        const float2 x = xr[j - u + 7];
+                        acc[j].x = fmaf(x.x, h[u].x, acc[j].x);  acc[j].x = fmaf(-x.y, p, acc[j].x);
+                        acc[j].y = fmaf(x.x, p, acc[j].y);       acc[j].y = fmaf(x.y, qq, acc[j].y);
+                    }
+                }
+#pragma unroll
+                for (int i = TT + 6; i >= 8; i--) xr[i] = xr[i - 8];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TT; j++)
+            if (j0 + j < a.T) a.part[(((size_t) s * a.T + j0 + j) * a.nq + q) * M + col] = acc[j];
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, int nq, float2 *buf, int lane)
 {

@@ -437,3 +437,24 @@ def test_multi_device_group_matches_single_engine():
     m.reset()
     assert np.array_equal(m.process(x), ref)
     m.close()
+
+
+@pytest.mark.parametrize("B,Lh,T", [(256, 5000, 40), (128, 3000, 33), (512, 6000, 16), (64, 900, 50), (1024, 9000, 17)])
+def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
+    """k_cmac_tiled1 (one bin per lane, 16 outputs per tile) is chosen only for HBM-sized batches; force it here
+    (IRB_TILED1=1) on small cases and compare with the oracle and with the default tiled kernel."""
+    I, C = 3, 2
+    x = _streams(I, C, T * B, 555)
+    irs = [np.stack([decaying_ir(560 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    outs = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("IRB_TILED1", force)
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            outs.append(eng.process(x))
+    assert rel_rms(outs[0], outs[1]) < 2e-6
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
