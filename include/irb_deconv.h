@@ -74,10 +74,14 @@ double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sa
 int    irb_sweep_lin_fadeout(double *sweep, int n, int index);
 
 /* The one-shot entry points (here and irb_convolve_periodic) keep the calling thread's most recent FFT plan /
- * engine (device buffers, twiddle tables, stream) for reuse; this releases them. */
+ * engine (device buffers, twiddle tables, stream) for reuse; this releases them.  No reference counterpart
+ * (the reference constructs a dsp::FFT per call, fp/tools.cpp:331,359). */
 void irb_release_cached_plans(void);
 
-/* ---- reusable plan with device-resident buffers (bench, repeated transforms) ---- */
+/* ---- reusable plan with device-resident buffers (bench, repeated transforms) ----
+ * The counterpart of constructing juce::dsp::FFT objects once and reusing them (fp/convolution.cpp:73-77);
+ * forward/inverse are performRealOnlyForwardTransform / performRealOnlyInverseTransform (fp/tools.cpp:335,363)
+ * on device buffers; buffers / synchronize / mark / elapsed_ms have no reference counterpart. */
 int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
 void irb_lfft_destroy(irb_lfft *p);
 /* scratch owned by the plan: d_time [max_batch][N] floats, d_spec [max_batch][2N] floats */

@@ -118,16 +118,17 @@ int  irb_fdl_reset(irb_fdl *h);
  * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.     */
 int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
 
-/* Same with one packed host buffer per direction: stream s, block j at in + s*stride + j*block (floats).
+/* Same steps (fp/convolution.cpp:128-213; RT Source/PluginProcessor.cpp:428-510) with one packed host buffer per
+ * direction: stream s, block j at in + s*stride + j*block (floats).
  * No per-stream packing on the host; with buffers from irb_host_alloc (pinned) the transfers run at PCIe
  * speed.  in == out is allowed.  Blocks until done.                                  */
 int  irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride, int n_blocks);
 
-/* Page-locked host memory for the packed API (hipHostMalloc / hipHostFree).          */
+/* Page-locked host memory for the packed API (hipHostMalloc / hipHostFree); no reference counterpart. */
 void *irb_host_alloc(size_t bytes);
 void  irb_host_free(void *p);
 
-/* Same with device-resident audio: stream s, block j lives at
+/* Same steps (fp/convolution.cpp:128-213) with device-resident audio: stream s, block j lives at
  * d_in + s*stride + j*block (floats); likewise d_out.  Asynchronous.            */
 int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks);
 
@@ -140,7 +141,7 @@ int  irb_fdl_synchronize(irb_fdl *h);
 int  irb_fdl_mark(irb_fdl *h, int slot);
 int  irb_fdl_elapsed_ms(irb_fdl *h, float *ms);
 
-/* Device scratch owned by the handle, for callers that want device-resident
+/* Device scratch owned by the handle (no reference counterpart), for callers that want device-resident
  * audio without another allocator: [streams][max_blocks_per_call*block] floats
  * each.  Pointers stay valid until destroy.                                      */
 int  irb_fdl_device_io(irb_fdl *h, float **d_in, float **d_out, long *stride);
@@ -161,7 +162,8 @@ int  irb_convolve_periodic(int device,
                            float *const *out);
 
 /* ---- several GPUs from one host process ------------------------------------------------------------------
- * Instances never communicate, so a group of handles shards them by contiguous ranges: device d of D owns
+ * No reference counterpart (the reference is one plug-in instance on one CPU thread); the per-instance work is
+ * the same as irb_fdl_* above.  Instances never communicate, so a group of handles shards them by contiguous ranges: device d of D owns
  * instances [d*I/D, (d+1)*I/D) (balanced to within one).  No peer access, no collective.  irb_fdl_multi_process
  * enqueues pack/H2D/kernels/D2H on every device's stream from the calling thread and only then waits, so the
  * devices run concurrently.  `devices` may name a device more than once (tests on a one-GPU box do). */
@@ -169,11 +171,12 @@ typedef struct irb_fdl_multi irb_fdl_multi;
 int  irb_fdl_multi_create(const irb_fdl_config *cfg /* n_instances = total over all devices; .device, .stream ignored */,
                           const int *devices, int n_devices, irb_fdl_multi **out);
 void irb_fdl_multi_destroy(irb_fdl_multi *m);
-/* which shard owns `instance`, and its index there */
+/* which shard owns `instance`, and its index there (no reference counterpart) */
 int  irb_fdl_multi_owner(const irb_fdl_multi *m, int instance, int *shard, int *local_instance);
 int  irb_fdl_multi_set_ir(irb_fdl_multi *m, int instance, const float *const *ir, int ir_channels, int len);
 int  irb_fdl_multi_reset(irb_fdl_multi *m);
-/* in/out: one host pointer per GLOBAL stream (instance*channels + ch), n_blocks*block samples each */
+/* the FDL steps of irb_fdl_process (fp/convolution.cpp:128-213) on every shard; in/out: one host pointer per
+ * GLOBAL stream (instance*channels + ch), n_blocks*block samples each */
 int  irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const *out, int n_blocks);
 
 /* ---- processBlock-shaped adapter ---------------------------------------------
@@ -190,7 +193,8 @@ int  irb_rt_prepare_to_play(irb_rt *p, int samples_per_block);
 int  irb_rt_release_resources(irb_rt *p);
 /* IRtoConvolve (:411-414): host samples, copied; must hold >= partitions*block.  */
 int  irb_rt_set_ir(irb_rt *p, const float *ir, int len);
-/* buffer: planar host [channels][n], processed in place.                         */
+/* The IRCAP_IDLE branch itself (Source/PluginProcessor.cpp:408-562).  buffer: planar host [channels][n],
+ * processed in place.                                                               */
 int  irb_rt_process_block(irb_rt *p, float *const *buffer, int n);
 /* Replaces processBlockBypassed (Source/PluginProcessor.cpp:584-590): host-only ring that keeps the plug-in's
  * block delay while bypassed.  n must equal the prepared samples_per_block.            */
