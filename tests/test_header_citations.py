@@ -8,17 +8,19 @@ CITE = re.compile(r"(fp/[A-Za-z]+\.(cpp|hpp):\d+|Source/PluginProcessor\.(cpp|h)
 
 
 def _functions_with_comments(path):
+    """(function name, the block comment that documents it): block comments start a line; comments inside a
+    parameter list or trailing a declaration do not document the declarations that follow."""
     src = open(path).read()
-    # split into (comment block, following declarations up to the next comment block)
-    parts = re.split(r"(/\*.*?\*/)", src, flags=re.S)
-    comment = ""
-    out = []
-    for p in parts:
-        if p.startswith("/*"):
-            comment = p
-        else:
-            for name in re.findall(r"\b(irb_[a-z_0-9]+)\s*\(", p):
-                out.append((name, comment))
+    out, comment, pos = [], "", 0
+    for m in re.finditer(r"/\*.*?\*/", src, flags=re.S):
+        for name in re.findall(r"\b(irb_[a-z_0-9]+)\s*\(", src[pos:m.start()]):
+            out.append((name, comment))
+        line_start = src.rfind("\n", 0, m.start()) + 1
+        if src[line_start:m.start()].strip() == "":
+            comment = m.group(0)
+        pos = m.end()
+    for name in re.findall(r"\b(irb_[a-z_0-9]+)\s*\(", src[pos:]):
+        out.append((name, comment))
     return out
 
 
