@@ -84,10 +84,12 @@ void irb_release_cached_plans(void);
  * on device buffers; buffers / synchronize / mark / elapsed_ms have no reference counterpart. */
 int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
 void irb_lfft_destroy(irb_lfft *p);
-/* scratch owned by the plan: d_time [max_batch][N] floats, d_spec [max_batch][2N] floats */
+/* scratch owned by the plan (no reference counterpart): d_time [max_batch][N] floats, d_spec [max_batch][2N] floats */
 int  irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec);
+/* performRealOnlyForwardTransform / performRealOnlyInverseTransform (fp/tools.cpp:335,363) on device buffers */
 int  irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int batch);   /* asynchronous */
 int  irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int batch);  /* asynchronous */
+/* stream wait and hipEvent timing for bench.py; no reference counterpart */
 int  irb_lfft_synchronize(irb_lfft *p);
 int  irb_lfft_mark(irb_lfft *p, int slot);
 int  irb_lfft_elapsed_ms(irb_lfft *p, float *ms);
