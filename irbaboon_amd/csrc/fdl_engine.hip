@@ -51,6 +51,7 @@ struct irb_fdl {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
+    int tiled_splits_override = 0;           // tuning: IRB_TILED_SPLITS, read once at create
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
@@ -118,7 +119,7 @@ int tiled_splits(const irb_fdl *h, int T)
     const int by_work = std::max(1, (h->Ppad / kTT) / (stripes * 2));
     const long wgs = (long) h->S * ntiles;
     const int by_chip = (int) std::max<long>(1, (768 + wgs - 1) / wgs);
-    if (const char *v = std::getenv("IRB_TILED_SPLITS")) return std::max(1, std::min(by_work, std::atoi(v)));   // tuning override
+    if (h->tiled_splits_override > 0) return std::max(1, std::min(by_work, h->tiled_splits_override));   // IRB_TILED_SPLITS
     return std::max(1, std::min(by_work, by_chip));
 }
 
@@ -255,6 +256,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
     h->tiled1 = h->nt;
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
+    if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };
