@@ -600,7 +600,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     }
     if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2)))          // :28-42
         return fail(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
-    if (Lh == 0 || Lout <= 0) return IRB_OK;
+    if (Lh == 0 || La == 0 || Lout <= 0) return IRB_OK;     // nothing to convolve: the cleared output is the answer
     // :52 -- the reference takes ceil of a float ratio; samples beyond P*B are never read (:106-118)
     const int P = (int) std::ceil((float) Lh / (float) B);
     const int Lh_eff = (int) std::min<long>(Lh, (long) P * B);
