@@ -10,6 +10,12 @@ replicates the configuration over `--instances` independent instances per GPU (d
 that the working set (1.5 MiB per instance) is far beyond the 256 MiB Infinity Cache and the
 kernel is measured against HBM.  Instances are sharded over GPUs with no collective (weak scaling).
 
+Two ways to run on N GPUs, same JSON line:
+  * `python bench.py --gpus N`                         ONE process, one irb_fdl engine per device, no RCCL at all
+                                                       (instances never communicate: the north star's "RCCL-free split");
+  * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+                                                       one rank per GPU; torch.distributed (RCCL) only for the
+                                                       barrier and the max-over-ranks of the step time.
 One JSON line on stdout (rank 0).  `value` counts channel-samples through the convolver with
 inputs and outputs resident in HBM.
 """
@@ -24,15 +30,30 @@ sys.path.insert(0, ROOT)
 
 B, LH = 256, 96000          # configs[1]: block 256, 2 s IR at 48 kHz
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+NB = 8                      # distinct input blocks kept resident per instance (cycled)
+
+
+def launch_mode(n_gpus, env):
+    """How this invocation drives its GPUs: ("ranks", world) under torchrun, else ("one-process", n_gpus).
+    Raises ValueError when torchrun's world size contradicts --gpus (a mis-typed command, not a mode)."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    if world > 1:
+        if world != n_gpus:
+            raise ValueError(f"--gpus {n_gpus} but torchrun started WORLD_SIZE={world} ranks")
+        return "ranks", world
+    if n_gpus < 1:
+        raise ValueError("--gpus must be >= 1")
+    return "one-process", n_gpus
 
 
 def cpu_baseline(seconds):
     """The CPU oracle (a port of the reference's convolvePeriodic loop, oracle/fp_oracle.c) timed
-    on one host core on a bounded sample of the same workload: one mono stream, B=256, Lh=96000."""
-    import numpy as np
+    on one host core on a bounded sample of the same workload: one mono stream, B=256, Lh=96000.
+    Built with -march=native on this machine; the flags are recorded."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from irbaboon_amd.synth import decaying_ir, white_noise
+    cflags = oracle.use_native()
     h = decaying_ir(18000, LH)[None]
     probe = white_noise(2000, LH)[None]
     oracle.convolve_periodic(probe[:, :LH // 8], h, B)            # warm up (page in the library, allocator)
@@ -44,7 +65,7 @@ def cpu_baseline(seconds):
     t0 = time.perf_counter()
     oracle.convolve_periodic(x, h, B)
     dt = time.perf_counter() - t0
-    return {"value": round(La / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+    return {"value": round(La / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port", "cflags": cflags,
             "sample": f"1 mono stream, B={B}, Lh={LH}, La={La} samples ({La // B}+375 block steps), {dt:.1f} s"}
 
 
@@ -67,6 +88,7 @@ def cpu_baseline_multicore(single, seconds):
         t.join()
     wall = time.perf_counter() - t0
     return {"value": round(cores * La / wall / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "cflags": single.get("cflags"),
             "sample": f"{cores} independent mono streams (one thread each), B={B}, Lh={LH}, La={La} each, {wall:.1f} s wall"}
 
 
@@ -78,6 +100,42 @@ def _timed_calls(eng, d_in, d_out, stride, T, reps):
         eng.process_device(d_in, d_out, stride, T)
     eng.mark(1)
     return eng.elapsed_ms() / reps
+
+
+def parity_spot(eng, np, x, first_instance, decaying_ir, picks, blocks=4):
+    """Before anything is timed: push `blocks` blocks through the SAME engine and the same one-block launch the timed
+    loop uses, download, and compare a few instances with float64 FFT convolution (scipy; not the oracle: this is
+    the product checking itself against the definition of the result).  Returns the worst relative RMS."""
+    import scipy.signal
+    d_in, d_out, stride = eng.device_io()
+    eng.reset()
+    for k in range(blocks):
+        eng.process_device(d_in + k * B * 4, d_out + k * B * 4, stride, 1)
+    eng.synchronize()
+    y = eng.download(d_out, eng.streams * stride).reshape(eng.streams, stride)[:, :blocks * B]
+    worst = 0.0
+    for i in picks:
+        h = decaying_ir(18000 + 2 * (first_instance + i), LH).astype(np.float64)
+        ref = scipy.signal.fftconvolve(x[i, :blocks * B].astype(np.float64), h)[:blocks * B]
+        worst = max(worst, float(np.sqrt(np.mean((y[i] - ref) ** 2) / np.mean(ref ** 2))))
+    eng.reset()
+    return worst
+
+
+def pcie_inclusive(eng, np, x, reps=30):
+    """The same workload through the host-buffer API (irb_fdl_process_packed: one pinned host array each way,
+    H2D + kernel + D2H + wait per step), wall clock.  Reported beside `value`, never as `value`."""
+    from irbaboon_amd.engine import pinned_empty
+    xin, yout = pinned_empty((eng.streams, B)), pinned_empty((eng.streams, B))
+    xin[:] = x[:, :B]
+    eng.process_packed(xin, yout)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.process_packed(xin, yout)
+    dt = (time.perf_counter() - t0) / reps
+    return {"Msamples_per_s": round(eng.streams * B / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 4),
+            "pcie_GBps_both_ways": round(2 * eng.streams * B * 4 / dt / 1e9, 2),
+            "note": "irb_fdl_process_packed, pinned host buffers, one block per instance per call, wall clock incl. H2D/D2H"}
 
 
 def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
@@ -94,14 +152,14 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
         ms = _timed_calls(e, di, do, st, T, reps)
         alg = I * C * T * e.info.algorithmic_bytes_per_block_step
         res[name] = {"Msamples_per_s": round(I * C * T * Bk / ms / 1e3, 1), "ms_per_call": round(ms, 4), "blocks_per_call": T,
-                     "algorithmic_GBps_streaming_model": round(alg / ms / 1e6, 1), "note": note}
+                     "splits": e.info.splits, "algorithmic_GBps_streaming_model": round(alg / ms / 1e6, 1), "note": note}
         e.close()
 
     run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 10,
         "ONE mono stream, whole 960000-sample signal in one call (time-tiled MAC); cache-resident, compute-bound")
     run("configs[1]_x2048_8_blocks_per_call", 2048, 1, 256, 96000, 8, 10,
         "2048 instances, 8 blocks per call: H and FDL rows are read once per 8 outputs")
-    run("configs[2]_stereo_10s_ir_streaming", 1, 2, 128, 480000, 1, 200,
+    run("configs[2]_stereo_10s_ir_streaming", 1, 2, 128, 480000, 1, 400,
         "stereo, B=128, P=3750, one block per call (split-P path, 14.6 MiB working set: Infinity-Cache resident)")
     run("configs[2]_stereo_10s_ir_offline", 1, 2, 128, 480000, 2048, 5, "same IRs, 2048 blocks per call (time-tiled)")
     run("configs[3]_1024_instances_b512_streaming", 1024, 1, 512, 96000, 1, 100,
@@ -109,8 +167,19 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     run("rt_layout_1024_stereo_instances_mono_ir", 1024, 2, 256, 96000, 1, 100,
         "stereo audio, IR channel 0 for both channels (the plug-in's real-time layout, Source/PluginProcessor.cpp:485): "
         "paired kernel loads each IR row once for both channels (3 rows per partition instead of 4)", ir_ch=1)
+    res.update(config5(dev, np))
+    return res
+
+
+def config5(dev, np):
+    """BASELINE configs[4]: 2^20-sample sweep capture -> IR extraction (deconvolve) + inversion (invertFilter):
+    the bare large FFT on device-resident data (hipEvents) and the one-shot chain calls (wall clock, host buffers,
+    PCIe both ways, plan cached after the first call)."""
     import irbaboon_amd as ib
-    plan = ib.LargeFft(1 << 20, 1, device=dev)
+    from irbaboon_amd.synth import decaying_ir, exp_sine_sweep
+    res = {}
+    N = 1 << 20
+    plan = ib.LargeFft(N, 1, device=dev)
     plan.forward(1)
     plan.inverse(1)
     plan.synchronize()
@@ -125,9 +194,34 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     plan.mark(1)
     i = plan.elapsed_ms() / 50
     res["configs[4]_2^20_real_fft"] = {"forward_us": round(f * 1e3, 1), "inverse_us": round(i * 1e3, 1),
-                                       "effective_GBps_min_traffic": round(8.0 * (1 << 20) / f / 1e6, 1),
-                                       "note": "single 2^20-point real FFT (four-step, 3 launches); latency-bound"}
+                                       "effective_GBps_min_traffic": round(8.0 * N / f / 1e6, 1),
+                                       "note": "single 2^20-point real FFT (four-step), device-resident; latency-bound"}
     plan.close()
+
+    sr = 48000
+    sweep = exp_sine_sweep(3 * N // 4, sr, 20.0, sr / 2, fade_from=(11.0 / 12.0) * sr / 2, n_total=N)
+    h = decaying_ir(77, 4096)
+    cap = np.fft.irfft(np.fft.rfft(sweep.astype(np.float64)) * np.fft.rfft(h.astype(np.float64), N), N).astype(np.float32)
+
+    def wall(fn, reps):
+        fn()                                        # first call builds the cached plan
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    t_raw = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=False, device=dev), 10)
+    t_smooth = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=True, device=dev), 5)
+    ir = ib.deconvolve(cap, sweep, sr, smoothing=False, device=dev)
+    t_inv = wall(lambda: ib.invertFilter(ir, sr, device=dev), 5)
+    # traffic the chain cannot avoid: two forward FFTs (read N, write N) + divide + inverse, all fp32
+    res["configs[4]_2^20_deconvolve_chain"] = {
+        "deconvolve_no_smoothing_ms": round(t_raw, 3), "deconvolve_default_3x_smoothing_ms": round(t_smooth, 3),
+        "invert_filter_ms": round(t_inv, 3), "samples": N,
+        "Msamples_per_s_default": round(N / t_smooth / 1e3, 1),
+        "note": "irb_deconvolve / irb_invert_filter one-shot calls on a 2^20-sample sweep capture (786432-sample sweep + silence, "
+                "4096-tap IR), wall clock from pageable host buffers incl. PCIe; fp/convolution.cpp:351-403, fp/ir.cpp:13-18"}
+    ib.lib().irb_release_cached_plans()
     return res
 
 
@@ -142,89 +236,139 @@ def main():
     ap.add_argument("--no-single", action="store_true")
     args = ap.parse_args()
 
+    try:
+        mode, world = launch_mode(args.gpus, os.environ)
+    except ValueError as e:
+        raise SystemExit(str(e))
+
     import numpy as np
-    import torch                      # plumbing: device sync + torch.distributed (RCCL) for barrier/max
+    import torch                      # plumbing: device sync; torch.distributed (RCCL) only in the torchrun mode
     from irbaboon_amd import FdlEngine, shard
     from irbaboon_amd.synth import decaying_ir, white_noise
 
-    ranks = shard.Ranks()
-    if ranks.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ranks.world}: for N > 1 launch one rank per GPU with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
+    ranks = shard.Ranks() if mode == "ranks" or os.environ.get("IRB_FORCE_DIST") == "1" else None
+    rank = ranks.rank if ranks else 0
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    dev = ranks.local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev)
+    rehearsal = None
+    if mode == "ranks":
+        devices = [ranks.local_rank % ndev]
+    else:
+        if world > ndev:
+            if os.environ.get("IRB_BENCH_SHARE_DEVICE") != "1":
+                raise SystemExit(f"--gpus {world} but only {ndev} HIP device(s) are visible "
+                                 f"(IRB_BENCH_SHARE_DEVICE=1 rehearses the N-shard path on the devices present)")
+            rehearsal = f"{world} shards on {ndev} device(s): a rehearsal of the multi-GPU code path, not a scaling measurement"
+        devices = [d % ndev for d in range(world)]
 
-    I, K, W, NB = args.instances, args.steps, args.warmup, 8
-    eng = FdlEngine(I, 1, B, LH, max_blocks_per_call=NB, device=dev)
-    info = eng.info
-    lo = ranks.rank * I               # weak scaling: every GPU owns I instances of its own
-    for i in range(I):
-        eng.set_ir(i, decaying_ir(18000 + 2 * (lo + i), LH))
-    d_in, d_out, stride = eng.device_io()
-    x = np.stack([white_noise(2000 + 2 * (lo + i), NB * B) for i in range(I)])
-    eng.upload(d_in, x)
+    I, K, W = args.instances, args.steps, args.warmup
+    engines, xs = [], []
+    for slot, dev in enumerate(devices):
+        shard_id = rank if mode == "ranks" else slot
+        eng = FdlEngine(I, 1, B, LH, max_blocks_per_call=NB, device=dev)
+        lo = shard_id * I             # weak scaling: every GPU owns I instances of its own, distinct IRs
+        for i in range(I):
+            eng.set_ir(i, decaying_ir(18000 + 2 * (lo + i), LH))
+        x = np.stack([white_noise(2000 + 2 * (lo + i), NB * B) for i in range(I)])
+        eng.upload(eng.device_io()[0], x)
+        engines.append((eng, lo))
+        xs.append(x)
+    info = engines[0][0].info
+
+    # parity spot check on the very kernel that is timed next (every shard; a few instances each)
+    picks = sorted({0, 1, I // 2, I - 1})
+    spot = max(parity_spot(eng, np, xs[n], lo, decaying_ir, picks) for n, (eng, lo) in enumerate(engines))
+    if not spot < 1e-5:
+        raise SystemExit(f"parity spot check failed before timing: rel RMS {spot:.3e} >= 1e-5")
+
+    ios = [eng.device_io() for eng, _ in engines]
 
     def step(k):
         off = (k % NB) * B * 4
-        eng.process_device(d_in + off, d_out + off, stride, 1)
+        for (eng, _), (d_in, d_out, stride) in zip(engines, ios):
+            eng.process_device(d_in + off, d_out + off, stride, 1)
+
+    def sync_all():
+        for eng, _ in engines:
+            eng.synchronize()
+        for dev in sorted(set(devices)):
+            torch.cuda.synchronize(dev)
+        if ranks:
+            ranks.barrier()
 
     for k in range(W):
         step(k)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    ranks.barrier()
+    sync_all()
     t0 = time.perf_counter()
-    eng.mark(0)
+    for eng, _ in engines:
+        eng.mark(0)
     for k in range(K):
         step(W + k)
-    eng.mark(1)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    ranks.barrier()
+    for eng, _ in engines:
+        eng.mark(1)
+    sync_all()
     wall = time.perf_counter() - t0
-    ev_ms = eng.elapsed_ms()
-    wall = ranks.max(wall)
-    ev_ms_max = ranks.max(ev_ms)
+    ev_ms = [eng.elapsed_ms() for eng, _ in engines]          # per device: its own K launches on its own stream
+    if ranks:
+        wall = ranks.max(wall)
+        ev_ms_max = ranks.max(max(ev_ms))
+        ev_ms_min = -ranks.max(-min(ev_ms))
+    else:
+        ev_ms_max, ev_ms_min = max(ev_ms), min(ev_ms)
 
-    total_samples = float(I) * ranks.world * B * K
+    total_samples = float(I) * world * B * K
     value = total_samples / wall / 1e6
-    launches_per_step = 1 if info.splits <= 1 else 3
-    kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step
+    three = bool(os.environ.get("IRB_SPLIT_3LAUNCH", "0") not in ("", "0"))
+    launches_per_step = 1 if (info.splits <= 1 or not three) else 3
+    kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step; the slowest device
     alg_bytes = I * info.algorithmic_bytes_per_block_step          # per launch: I * (8*P*N + 16*B)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             if t.get("instances") == I:
                 traffic = t.get("hbm_bytes_per_launch")
+                traffic_source = ("static: profiles/hbm_traffic.json (" + str(t.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"))
+                                  + "), NOT measured by this run")
         except Exception:
             traffic = None
 
     out = {
         "metric": "Msamples/s (48 kHz, 256-blk, 2 s IR); achieved HBM GB/s vs roofline",
-        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ranks.world, "steps": K, "warmup": W,
+        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1] geometry (mono, B={B}, Lh={LH}, P={info.partitions}, N={info.fft_len}) "
                                f"x {I} independent instances per GPU, streaming: 1 block per instance per step",
                    "instances_per_gpu": I, "block": B, "ir_len": LH, "partitions": info.partitions,
-                   "fft_len": info.fft_len, "parallelism": f"instance-shard x{ranks.world} (no collective)",
+                   "fft_len": info.fft_len, "parallelism": f"instance-shard x{world} (no collective)",
+                   "launch_mode": "one rank per GPU (torchrun; RCCL for barrier + max only)" if mode == "ranks"
+                                  else "one process, one engine per device, no RCCL",
                    "launches_per_step": launches_per_step, "device_bytes_per_gpu": int(info.device_bytes)},
-        "roofline": {"bound": "hbm", "kernel": "k_step_fused<512>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_step_fused<512,2,true>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kern_ms, 4)},
+        "parity_spot": {"rel_rms_vs_float64": float(f"{spot:.3e}"), "tolerance": 1e-5, "instances_checked": len(picks) * len(engines),
+                        "note": "4 one-block steps through the timed kernel before timing, vs float64 FFT convolution"},
+        "per_gpu": {"Msamples_per_s": [round(I * B * K / ms / 1e3, 1) for ms in ev_ms] if not ranks or world == 1 else None,
+                    "kernel_ms_min": round(ev_ms_min / K, 4), "kernel_ms_max": round(ev_ms_max / K, 4)},
     }
+    if rehearsal:
+        out["rehearsal"] = rehearsal
 
-    if ranks.rank == 0 and ranks.world == 1 and not args.no_single:
+    solo = rank == 0 and world == 1
+    if solo and not args.no_single:
+        out["pcie_inclusive"] = pcie_inclusive(engines[0][0], np, xs[0])
         # the literal configs[1]: ONE mono stream (cache-resident, launch/latency-bound)
+        dev = devices[0]
         one = FdlEngine(1, 1, B, LH, max_blocks_per_call=NB, device=dev)
         one.set_ir(0, decaying_ir(18000, LH))
         di, do, st = one.device_io()
-        one.upload(di, x[0])
+        one.upload(di, xs[0][0])
         for k in range(50):
             one.process_device(di + (k % NB) * B * 4, do + (k % NB) * B * 4, st, 1)
         one.synchronize()
@@ -238,17 +382,18 @@ def main():
                                 "us_per_block": round(dt1 / n1 * 1e6, 2), "splits": one.info.splits,
                                 "note": "one mono stream, one block per step, 1.5 MiB working set (cache-resident)"}
         one.close()
-
-    if ranks.rank == 0 and ranks.world == 1 and not args.no_single:
-        eng.close()
+        for eng, _ in engines:
+            eng.close()
         out["other_configs"] = other_configs(dev, np, FdlEngine, decaying_ir, white_noise)
 
-    if ranks.rank == 0 and ranks.world == 1 and not args.no_cpu:
+    if solo and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         out["cpu_baseline_all_cores"] = cpu_baseline_multicore(out["cpu_baseline"], min(4.0, args.cpu_seconds))
-    eng.close()
-    ranks.close()
-    if ranks.rank == 0:
+    for eng, _ in engines:
+        eng.close()
+    if ranks:
+        ranks.close()
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
 

@@ -8,6 +8,7 @@
 #include "irb_fdl.h"
 
 #include <cstdio>
+#include <vector>
 
 namespace irb {
 
@@ -17,7 +18,8 @@ class RtConvolverT
 public:
     // ctor (Source/PluginProcessor.cpp:57-82): channels = generalInputAudioChannels, block = processBlockSize,
     // irRingLen = makeupIRLengthSamples (fixes irPartitions, :225); default IR = unit delta at sample 100 (:46)
-    RtConvolverT(int device, int channels, int processBlockSize, int makeupIRLengthSamples) : nch(channels)
+    RtConvolverT(int device, int channels, int processBlockSize, int makeupIRLengthSamples)
+        : nch(channels), ptrs((size_t) (channels > 0 ? channels : 0), nullptr)     // sized once: processBlock never allocates
     {
         if (irb_rt_create(device, channels, processBlockSize, makeupIRLengthSamples, &rt) != IRB_OK) report();
     }
@@ -43,17 +45,15 @@ public:
     // reference's error convention.  Output gain and limiter (:567-574) stay with the caller.
     void processBlock(Buffer &buffer)
     {
-        float *ptrs[16];
-        for (int c = 0; c < nch && c < 16; ++c) ptrs[c] = buffer.getWritePointer(c);
-        if (irb_rt_process_block(rt, ptrs, buffer.getNumSamples()) != IRB_OK) { report(); buffer.clear(); }
+        for (int c = 0; c < nch; ++c) ptrs[(size_t) c] = buffer.getWritePointer(c);
+        if (irb_rt_process_block(rt, ptrs.data(), buffer.getNumSamples()) != IRB_OK) { report(); buffer.clear(); }
     }
 
     // processBlockBypassed (:584-590)
     void processBlockBypassed(Buffer &buffer)
     {
-        float *ptrs[16];
-        for (int c = 0; c < nch && c < 16; ++c) ptrs[c] = buffer.getWritePointer(c);
-        if (irb_rt_process_block_bypassed(rt, ptrs, buffer.getNumSamples()) != IRB_OK) report();
+        for (int c = 0; c < nch; ++c) ptrs[(size_t) c] = buffer.getWritePointer(c);
+        if (irb_rt_process_block_bypassed(rt, ptrs.data(), buffer.getNumSamples()) != IRB_OK) report();
     }
 
     int latency() const { return irb_rt_latency(rt); }
@@ -63,6 +63,7 @@ private:
     static void report() { std::fprintf(stderr, "irb_rt: %s\n", irb_last_error()); }
     irb_rt *rt = nullptr;
     int nch;
+    std::vector<float *> ptrs;          // one pointer per channel of the processor (every channel, not the first 16)
 };
 
 }  // namespace irb

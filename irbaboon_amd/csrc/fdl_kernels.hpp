@@ -518,7 +518,11 @@ __global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *_
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int set = a.set_of_stream[s];
     const int np = a.np_of_set[set];
-    const int kb = (int) ((long) np * j / a.splits), ke = (int) ((long) np * (j + 1) / a.splits);
+    // Partition 0 pairs with the block that split 0 transforms in THIS launch, so it always belongs to split 0
+    // (through LDS); only the older partitions [1, np) are divided over the splits.  np comes from the IR in use,
+    // splits from the engine's capacity: np < splits just leaves some splits with an empty range.
+    const int nold = np > 0 ? np - 1 : 0;
+    const int kb = 1 + (int) ((long) nold * j / a.splits), ke = 1 + (int) ((long) nold * (j + 1) / a.splits);
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *_
 #pragma unroll
     for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
-    mac_range<N, 4>(H4, X4, (j == 0 && kb == 0) ? 1 : kb, ke, a.head, a.R, acc, dc);
+    mac_range<N, 4>(H4, X4, kb, ke, a.head, a.R, acc, dc);
     __syncthreads();                                   // twiddles (and split 0's block) are in LDS
 
     if (j == 0) {
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *_
             wave_split_forward<M>(lds.buf, lds.tw, lane, [&](int b, float2 v) { lds.scratch[b] = v; ring[b] = v; });
         }
         __syncthreads();
-        if (ke > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
+        if (np > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
             const int col = threadIdx.x;
 #pragma unroll
             for (int c = 0; c < G::CPT; c++) {

@@ -17,6 +17,23 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
 
 
+def use_native():
+    """bench.py's cpu_baseline: rebuild the oracle with -march=native ON this machine and load that build
+    (call before the first lib()).  Returns the compile command line; falls back to the portable build
+    (and says so) when there is no compiler."""
+    global _SO, _lib
+    try:
+        subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "native"])
+        flags = subprocess.check_output(["make", "-s", "-C", _ORACLE_DIR, "print-native-cflags"], text=True).strip()
+        _SO, _lib = os.path.join(_ORACLE_DIR, "libfp_oracle_native.so"), None
+        return flags
+    except Exception:
+        try:
+            return subprocess.check_output(["make", "-s", "-C", _ORACLE_DIR, "print-cflags"], text=True).strip() + " (prebuilt)"
+        except Exception:
+            return "prebuilt libfp_oracle.so (-O3 -march=x86-64-v2)"
+
+
 def _load():
     if not os.path.exists(_SO):
         build()

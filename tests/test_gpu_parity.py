@@ -39,14 +39,18 @@ ENGINE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("tmax", [1, 7], ids=["step", "tiled7"])
 @pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, 0],
                          ids=["fused", "split", "split3", "auto"])
 @pytest.mark.parametrize("case", ENGINE_CASES, ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
-def test_engine_streaming_matches_oracle(case, flags):
+def test_engine_streaming_matches_oracle(case, flags, tmax):
+    """tmax=1: every block is a one-block step, so `flags` really selects k_step_fused / k_step_fused_pair /
+    k_step_split / the three-launch split kernels; tmax=7: chunks of 7 blocks go through the time-tiled kernels
+    (k_push_fft_batch, k_cmac_tiled, k_ifft_ola_batch) and only a 1-block remainder is a step."""
     I, C, Cir, B, Lh, T = case
     x = _streams(I, C, T * B, 100)
     irs = [np.stack([decaying_ir(9000 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
-    with FdlEngine(I, C, B, Lh, max_blocks_per_call=7, flags=flags) as eng:
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=tmax, flags=flags) as eng:
         for i in range(I):
             eng.set_ir(i, irs[i])
         y = eng.process(x)
@@ -473,3 +477,128 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
         ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
         for c in range(C):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
+
+
+# ---- the kernels the bench numbers come from (they must be output-checked, not only timed) ----
+
+@pytest.mark.parametrize("case", [(3, 1, 1, 128, 2000, 12), (3, 1, 1, 256, 9000, 10), (2, 1, 1, 512, 9000, 8),
+                                  (2, 2, 2, 256, 5000, 9), (3, 2, 1, 256, 9000, 10), (2, 2, 1, 128, 3000, 11),
+                                  (2, 2, 1, 512, 7000, 6)],
+                         ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
+def test_non_temporal_fused_and_pair_kernels(monkeypatch, case):
+    """k_step_fused<N,2,true> and k_step_fused_pair<N,true> (non-temporal row loads) are chosen only for working
+    sets beyond the Infinity Cache -- the bench's headline kernel.  Force them (IRB_FUSED_NT=1, read at create) on
+    small cases: N = 256, 512, 1024; mono, stereo IR (unpaired) and stereo audio + mono IR (paired)."""
+    I, C, Cir, B, Lh, T = case
+    x = _streams(I, C, T * B, 6100)
+    irs = [np.stack([decaying_ir(6200 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
+    outs = []
+    for nt in ("1", "0"):
+        monkeypatch.setenv("IRB_FUSED_NT", nt)
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=1, flags=_lib.FORCE_FUSED) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            outs.append(eng.process(x))
+    assert np.array_equal(outs[0], outs[1])          # same arithmetic, only the cache policy of the loads differs
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
+
+
+def test_bench_workload_kernel_at_full_geometry():
+    """The bench workload itself, scaled down in instance count only: mono, B=256, Lh=96000 (P=375, N=512), enough
+    instances that the engine picks the non-temporal fused kernel BY ITSELF (working set > 256 MiB), one block per
+    call.  Checked against float64 FFT convolution for a few instances and by the linearity checksum over all."""
+    I, B, Lh, T = 192, 256, 96000, 6
+    x1 = white_noise(8000, T * B)
+    x = np.broadcast_to(x1, (I, T * B)).copy()
+    with FdlEngine(I, 1, B, Lh, max_blocks_per_call=1) as eng:
+        assert eng.info.splits == 1 and eng.info.partitions == 375 and eng.info.fft_len == 512
+        assert eng.info.device_bytes > (256 << 20)
+        hsum, keep = np.zeros(Lh, np.float64), {}
+        for i in range(I):
+            h = decaying_ir(8100 + 2 * i, Lh)
+            hsum += h
+            if i in (0, 1, 100, I - 1):
+                keep[i] = h
+            eng.set_ir(i, h)
+        y = eng.process(x)
+    for i, h in keep.items():
+        assert rel_rms(y[i], scipy.signal.fftconvolve(x1.astype(np.float64), h.astype(np.float64))[:T * B]) < RMS_TOL
+    assert rel_rms(y.astype(np.float64).sum(axis=0), scipy.signal.fftconvolve(x1.astype(np.float64), hsum)[:T * B]) < RMS_TOL
+
+
+def test_cfg3_streaming_geometry_split_path():
+    """BASELINE configs[2] as the bench times it: stereo, B=128, 10 s IR (P=3750), ONE block per call, auto splits
+    (the single-launch split-P path).  More than P+64 steps so every ring slot wraps and every partition carries
+    signal.  Reference: float64 FFT convolution (the oracle would take minutes) and the time-tiled path."""
+    B, Lh = 128, 480000
+    T = 3750 + 90
+    x = np.stack([white_noise(3100, T * B), white_noise(3101, T * B)])
+    h = np.stack([decaying_ir(27000, Lh), decaying_ir(27001, Lh)])
+    with FdlEngine(1, 2, B, Lh, max_blocks_per_call=1) as eng:
+        assert eng.info.partitions == 3750 and eng.info.splits > 1
+        eng.set_ir(0, h)
+        y = eng.process(x)
+    for c in range(2):
+        ref = scipy.signal.fftconvolve(x[c].astype(np.float64), h[c].astype(np.float64))[:T * B]
+        assert rel_rms(y[c], ref) < RMS_TOL
+        assert rel_rms(y[c, -64 * B:], ref[-64 * B:]) < RMS_TOL       # the steps after the ring has wrapped
+    with FdlEngine(1, 2, B, Lh, max_blocks_per_call=512) as til:
+        til.set_ir(0, h)
+        assert rel_rms(til.process(x), y) < 2e-6
+
+
+@pytest.mark.parametrize("flags", [_lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, 0], ids=["split", "split3", "auto"])
+def test_split_path_with_fewer_partitions_than_splits(flags):
+    """The split count comes from the engine's CAPACITY (max_ir_len), the partitions in use from the IR that was
+    set.  An IR with np < splits used to leave partition 0 to a later split, which read ring slot `head` while
+    split 0 was still writing it.  np in {1, 2, splits-1, splits, splits+1} and a P=1 engine."""
+    B, cap = 128, 480000
+    T = 12
+    x = _streams(1, 2, T * B, 7300)
+    with FdlEngine(1, 2, B, cap, max_blocks_per_call=1, flags=flags) as eng:
+        sp = eng.info.splits
+        assert sp >= 2
+        for np_ in sorted({1, 2, sp - 1, sp, sp + 1, 3 * sp + 1}):
+            if np_ < 1:
+                continue
+            Lh = np_ * B - 5
+            h = np.stack([decaying_ir(7400 + np_, Lh), decaying_ir(7401 + np_, Lh)])
+            eng.reset()
+            eng.set_ir(0, h)
+            y = eng.process(x)
+            ref, _ = oracle.convolve_periodic(x, h, B)
+            for c in range(2):
+                assert rel_rms(y[c], ref[c, :T * B]) < RMS_TOL, (np_, sp)
+    with FdlEngine(2, 1, 256, 200, max_blocks_per_call=1, flags=_lib.FORCE_SPLIT) as one:      # P = 1, splits forced >= 2
+        assert one.info.partitions == 1 and one.info.splits >= 2
+        xs = _streams(2, 1, 8 * 256, 7500)
+        hs = [decaying_ir(7600 + i, 200) for i in range(2)]
+        for i in range(2):
+            one.set_ir(i, hs[i])
+        y = one.process(xs)
+        for i in range(2):
+            ref, _ = oracle.convolve_periodic(xs[i:i + 1], hs[i][None], 256)
+            assert rel_rms(y[i], ref[0, :8 * 256]) < RMS_TOL
+
+
+def test_bench_multi_gpu_code_path_rehearsal():
+    """`python bench.py --gpus 2` as the driver types it, on this one-GPU box: two shards share the device
+    (IRB_BENCH_SHARE_DEVICE=1), so the N-engine loop, the per-device events and the parity spot check all run;
+    the line says it is a rehearsal.  One process, no torch.distributed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IRB_BENCH_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--instances", "96", "--no-cpu", "--no-single"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and "rehearsal" in d and d["config"]["launch_mode"].startswith("one process")
+    assert d["parity_spot"]["rel_rms_vs_float64"] < 1e-5 and d["parity_spot"]["instances_checked"] == 8
+    assert len(d["per_gpu"]["Msamples_per_s"]) == 2 and d["value"] > 0
+    assert abs(d["value"] - 2 * 96 * 256 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
