@@ -45,6 +45,7 @@ extern "C" {
 #define IRB_FDL_FORCE_SPLIT   0x2u  /* always split the partitions over workgroups   */
 #define IRB_FDL_SPLIT_3LAUNCH 0x4u  /* split path as three launches (no in-kernel hand-off) */
 #define IRB_FDL_NO_PAIRING    0x8u  /* never share IR rows between the two channels of an instance */
+#define IRB_FDL_FORCE_COLS    0x10u /* always the column-sliced single-launch step (k_step_cols)   */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */

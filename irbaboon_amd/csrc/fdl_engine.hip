@@ -55,6 +55,9 @@ struct irb_fdl {
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
+    int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
+                                             // `splits` then counts partition splits (workgroups per stream = CS * splits)
+    bool cols_sc1 = true;                    // its hand-off: write-through slices (grid <= one workgroup per CU) or fences
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
     unsigned flags = 0;
@@ -93,19 +96,59 @@ int dev_alloc(irb_fdl *h, T **p, size_t n)
     default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
     }
 
-int choose_splits(const irb_fdl *h)
+int env_int(const char *name, int dflt)
 {
-    if (h->flags & IRB_FDL_FORCE_FUSED) return 1;
-    if (const char *v = std::getenv("IRB_SPLITS")) return std::max(1, std::atoi(v));    // tuning override
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+// One-block steps: which kernel family, and how a stream is spread over workgroups.
+//   fused  (colW = 0, splits = 1)  one workgroup per stream: HBM-sized batches (no hand-off at all)
+//   cols   (colW > 0)              column slices x partition splits, single launch (k_step_cols): few streams
+//                                  (latency) and mid-size batches that one workgroup per stream cannot fill the chip with
+//   split  (colW = 0, splits > 1)  the older partition-split kernels, kept behind IRB_FDL_FORCE_SPLIT
+void choose_path(irb_fdl *h)
+{
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
-    // latency path (few streams): measured optimum is 16..64 workgroups per stream with >= 16 partitions
-    // per stripe; more splits only lengthen the last arriver's slab sum (tools/perf_probe.py single)
-    const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
-    if (h->flags & IRB_FDL_FORCE_SPLIT) return std::max(2, by_work);
-    if (h->S >= 128) return 1;                                          // enough workgroups already: fused kernel
-    const int by_chip = std::max(1, 512 / h->S);
-    const int s = std::min(by_work, by_chip);
-    return s < 2 ? 1 : s;
+    h->colW = 0; h->splits = 1; h->cols_sc1 = true;
+    if (h->flags & IRB_FDL_FORCE_FUSED) return;
+    if (h->flags & IRB_FDL_FORCE_SPLIT) {
+        // measured optimum of that kernel: 16..64 workgroups per stream with >= 16 partitions per stripe
+        const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
+        h->splits = std::max(2, env_int("IRB_SPLITS", by_work));
+        return;
+    }
+    const bool force_cols = (h->flags & IRB_FDL_FORCE_COLS) != 0;
+    if (!force_cols && env_int("IRB_COLS", 1) == 0) {      // A/B switch: the round-1 heuristic (fused from 128 streams, else split)
+        if (h->S >= 128) return;
+        const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
+        const int sp = std::min(by_work, std::max(1, 512 / h->S));
+        h->splits = env_int("IRB_SPLITS", sp < 2 ? 1 : sp);
+        return;
+    }
+    // from two workgroups per CU on, the fused kernel runs at its HBM rate and needs no hand-off at all
+    if (!force_cols && h->S >= env_int("IRB_FUSED_FROM", 512)) return;
+    // column slice width: the narrowest of {4, 16, 64} float4 that keeps S * CS within one workgroup per CU; a
+    // 4-column slice is one 64-byte piece per row, a 64-column slice one fully coalesced KiB per wave
+    int W = 64;
+    for (int w : {4, 16, 64}) {
+        const int we = std::min(w, L);
+        if ((long) h->S * (L / we) <= 256) { W = w; break; }
+    }
+    W = env_int("IRB_COLW", W);
+    if (W != 4 && W != 16 && W != 64) W = 64;
+    const int we = std::min(W, L), CS = L / we, NS = irb::kThreads / we;
+    const long base = (long) h->S * CS;
+    // partition splits: fill the chip (latency regime: one workgroup per CU; batches: ~4 per CU), but leave every
+    // thread at least 4 partitions, and never more splits than the last arriver can sum in one round of loads
+    const int by_work = std::max(1, h->P / (NS * 4));
+    const long target = base <= 256 ? 256 : 1024;
+    int PS = (int) std::max<long>(1, std::min<long>(std::min(by_work, 16), target / base));
+    PS = std::max(1, env_int("IRB_PSPLITS", PS));
+    h->colW = W;
+    h->splits = PS;
+    // write-through hand-off is measured for one workgroup per CU; larger grids use the release/acquire form
+    h->cols_sc1 = env_int("IRB_COLS_SC1", base * PS <= 256 ? 1 : 0) != 0;
 }
 
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
@@ -135,8 +178,23 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     return a;
 }
 
+#define LAUNCH_COLS(W_, SC1_)                                                                                    \
+    FOR_N(h->N, irb::k_step_cols<NN, W_, SC1_><<<dim3(h->S * irb::ColsGeom<NN, W_>::CS * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets))
+
+int launch_cols(irb_fdl *h, const irb::StepArgs &a)
+{
+    if (h->cols_sc1) {
+        if (h->colW == 4) { LAUNCH_COLS(4, true); } else if (h->colW == 16) { LAUNCH_COLS(16, true); } else { LAUNCH_COLS(64, true); }
+    } else {
+        if (h->colW == 4) { LAUNCH_COLS(4, false); } else if (h->colW == 16) { LAUNCH_COLS(16, false); } else { LAUNCH_COLS(64, false); }
+    }
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
 int launch_step(irb_fdl *h, const irb::StepArgs &a)
 {
+    if (h->colW > 0) return launch_cols(h, a);
     if (h->splits <= 1) {
         // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
         // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
@@ -250,7 +308,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->Tmax = cfg->max_blocks_per_call;
     h->R = h->Tmax > 1 ? h->Ppad + h->Tmax + kTT : h->P;     // tiled path: P past blocks + the call's blocks + tile overhang
     h->flags = cfg->flags;
-    h->splits = choose_splits(h);
+    choose_path(h);
     h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
     if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
@@ -324,7 +382,8 @@ int irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info)
 {
     if (!h || !info) return fail(IRB_ERR_ARG, "null argument");
     info->fft_len = h->N; info->partitions = h->P; info->ring_slots = h->R; info->streams = h->S;
-    info->splits = h->splits; info->device_bytes = h->bytes;
+    info->splits = h->colW > 0 ? (h->M / 2 / std::min(h->colW, h->M / 2)) * h->splits : h->splits;
+    info->device_bytes = h->bytes;
     info->algorithmic_bytes_per_block_step = 8.0 * h->P * h->N + 16.0 * h->B;
     return IRB_OK;
 }

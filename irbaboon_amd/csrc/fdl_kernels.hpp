@@ -592,6 +592,268 @@ __global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_step_cols: the one-block step for FEW streams (latency path) and for mid-size batches, in ONE launch.
+// A workgroup owns a COLUMN slice of the spectrum (W float4 = 2W complex bins) and a partition range:
+//   grid = S * CS * PS,  CS = (N/4)/W column slices,  PS = partition splits (a.splits).
+// Thread (col, stripe) = (tid % W, tid / W) loads its column of up to 8 partitions (H row and FDL row, 16 B each)
+// in ONE round of loads; the 256/W stripes are combined by DPP row rotations + one LDS pass.  Slicing by columns
+// instead of by partitions shrinks the inter-workgroup hand-off from one whole spectrum row per workgroup
+// (k_step_split: splits * N*4 bytes per stream, read serially by the last arriver) to PS rows per stream.
+// The new block's forward FFT is done REDUNDANTLY by every workgroup of partition range 0 (the CUs are idle
+// anyway on this path) while its partition loads are in flight, so nothing waits for another workgroup's FFT;
+// each of them writes only its own column slice of the spectrum into the ring.
+// Hand-off (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", first table row): every
+// byte of the Y slices is stored with an sc1 (write-through) 8-byte store, the storing wave drains vmcnt,
+// workgroup barrier, ONE lane adds to the stream's unsharded agent-scope ticket counter, the workgroup whose
+// add came last loads every slice with sc1 8-byte loads after a barrier that wave joins.  No release or
+// acquire fence (their ~1.7 us each is what this path is made of), no spinning, no co-residency assumption.
+// ---------------------------------------------------------------------------------------------
+// XCD-aware workgroup id: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
+// its own 4 MiB L2); this bijection gives every XCD one contiguous range of ids instead, so workgroups
+// that share X/H rows (neighbouring time tiles) also share an L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for global loads in flight (a plain
+// __syncthreads() drains vmcnt too and would serialise the FFT behind the partition loads)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef unsigned long long u64_t;
+__device__ __forceinline__ void st_sc1(float2 *p, float2 v)
+{
+    u64_t bits;
+    __builtin_memcpy(&bits, &v, 8);
+    __hip_atomic_store(reinterpret_cast<u64_t *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_sc1(const float2 *p)
+{
+    const u64_t bits = __hip_atomic_load(reinterpret_cast<const u64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 v;
+    __builtin_memcpy(&v, &bits, 8);
+    return v;
+}
+
+template <int N, int W_>
+struct ColsGeom {
+    static constexpr int M = N / 2, L = M / 2;
+    static constexpr int W = W_ < L ? W_ : L;                   // float4 columns per slice
+    static constexpr int CS = L / W;                            // column slices per row
+    static constexpr int NS = kThreads / W;                     // stripes (partitions in flight per load slot)
+    static constexpr int G = W < 16 ? 16 : W;                   // threads that end up holding one partial row
+    static constexpr int NP = kThreads / G;                     // partial rows combined through LDS
+    static constexpr int U = 8;                                 // partitions per thread per round
+};
+
+template <int N, int W_, bool SC1>
+__global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__restrict__ tickets)
+{
+    using C = ColsGeom<N, W_>;
+    constexpr int M = C::M, W = C::W, CS = C::CS, NS = C::NS, U = C::U;
+    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_buf[M];                        // FFT work buffer; later the summed spectrum
+    __shared__ float2 l_spec[M];                       // packed spectrum of the new block
+    __shared__ float4 l_red[C::NP][W];
+    __shared__ float2 l_dc[C::NP];
+    __shared__ unsigned l_ticket;
+    const int PS = a.splits;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // neighbouring column slices share an XCD's L2
+    const int cs = wg % CS, ps = (wg / CS) % PS, s = wg / (CS * PS);
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const int col = tid % W, stripe = tid / W, gcol = cs * W + col;
+    const int set = a.set_of_stream[s];
+    const int np = a.np_of_set[set];
+    const int nold = np > 0 ? np - 1 : 0;              // partition 0 pairs with the block transformed in this launch
+    const int kb = 1 + (int) ((long) nold * ps / PS), ke = 1 + (int) ((long) nold * (ps + 1) / PS);
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    float2 *Xs = a.X + (size_t) s * a.R * M;
+    const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
+    const bool first = (ps == 0);                      // this workgroup also owns partition 0 of its columns
+
+    // ---- small loads first (they complete first): twiddles, the new block, H row 0.  All UNCONDITIONAL (clamped
+    // addresses, the zero padding is applied when the values are used): a predicated load makes hipcc wait for it
+    // at the join, in front of the partition loads ----
+    constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
+    constexpr int ZPL = M > kWave ? M / kWave : 1;
+    float2 twr[TWPT];
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) twr[i] = a.tw[min(tid + i * kThreads, N / 2 - 1)];
+    float zre[ZPL], zim[ZPL];
+    {
+        const float *xin = a.in + (size_t) s * a.in_stride;
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = 2 * (lane + i * kWave);
+            zre[i] = xin[min(n, a.B - 1)];
+            zim[i] = xin[min(n + 1, a.B - 1)];
+        }
+    }
+    const float4 h0 = H4[gcol];                        // row 0 always exists (used only when np > 0)
+
+    // ---- the partition loads of this thread: one round covers NS*U partitions of the range ----
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 dc = make_float2(0.f, 0.f);
+    // Loads are unconditional (a slot past the range re-reads a row this wave has just asked for and is masked when
+    // it is used): with branch-free issue hipcc counts vmcnt exactly, so the FFT below starts when the SMALL loads
+    // have landed while these are still in flight.
+    float4 h[U], x[U];
+    int k = kb + stripe;
+    auto issue = [&](int k0) {
+        const int kdup = k0 < ke ? k0 : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kk = k0 + u * NS < ke ? k0 + u * NS : kdup;
+            int slot = a.head - kk;
+            if (slot < 0) slot += a.R;
+            h[u] = H4[(size_t) kk * C::L + gcol];
+            x[u] = X4[(size_t) slot * C::L + gcol];
+        }
+    };
+    auto consume = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool live = k0 + u * NS < ke;
+            const float4 xv = live ? x[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dc.x += xv.x * h[u].x;
+            dc.y += xv.y * h[u].y;
+            acc.x += xv.x * h[u].x - xv.y * h[u].y;
+            acc.y += xv.x * h[u].y + xv.y * h[u].x;
+            acc.z += xv.z * h[u].z - xv.w * h[u].w;
+            acc.w += xv.z * h[u].w + xv.w * h[u].z;
+        }
+    };
+    issue(k);
+    __builtin_amdgcn_sched_barrier(0);                 // nothing that waits for a small load moves above the issue
+
+    // ---- twiddles (and the block) to LDS; forward FFT by wave 0 while the partition loads are in flight ----
+#pragma unroll
+    for (int i = 0; i < TWPT; i++) {
+        const int idx = tid + i * kThreads;
+        if (idx < N / 2) l_tw[idx] = twr[i];
+    }
+    if (first && wave == 0) {
+#pragma unroll
+        for (int i = 0; i < ZPL; i++) {
+            const int n = lane + i * kWave;
+            if (n < M) l_buf[n] = make_float2(2 * n < a.B ? zre[i] : 0.0f, 2 * n + 1 < a.B ? zim[i] : 0.0f);
+        }
+    }
+    lds_barrier();
+    if (first) {
+        if (wave == 0) {
+            wave_fft<M, false>(l_buf, l_tw, lane);
+            wave_split_forward<M>(l_buf, l_tw, lane, [&](int b, float2 v) { l_spec[b] = v; });
+        }
+        lds_barrier();
+        if (stripe == 0) {                             // partition 0 of this slice; the slice also goes into the ring
+            const float4 x0 = reinterpret_cast<const float4 *>(l_spec)[gcol];
+            reinterpret_cast<float4 *>(Xs + (size_t) a.head * M)[gcol] = x0;
+            if (np > 0) {
+                dc.x += x0.x * h0.x;
+                dc.y += x0.y * h0.y;
+                acc.x += x0.x * h0.x - x0.y * h0.y;
+                acc.y += x0.x * h0.y + x0.y * h0.x;
+                acc.z += x0.z * h0.z - x0.w * h0.w;
+                acc.w += x0.z * h0.w + x0.w * h0.z;
+            }
+        }
+    }
+    consume(k);
+    for (k += NS * U; k < ke; k += NS * U) {           // ranges longer than one round (long IRs, few splits)
+        issue(k);
+        consume(k);
+    }
+
+    // ---- combine the stripes: DPP rotations inside rows of 16 lanes, then NP partial rows through LDS ----
+    if constexpr (W <= 8) {
+        acc.x += dpp_row<0x128>(acc.x); acc.y += dpp_row<0x128>(acc.y); acc.z += dpp_row<0x128>(acc.z); acc.w += dpp_row<0x128>(acc.w);
+        dc.x += dpp_row<0x128>(dc.x); dc.y += dpp_row<0x128>(dc.y);
+    }
+    if constexpr (W <= 4) {
+        acc.x += dpp_row<0x124>(acc.x); acc.y += dpp_row<0x124>(acc.y); acc.z += dpp_row<0x124>(acc.z); acc.w += dpp_row<0x124>(acc.w);
+        dc.x += dpp_row<0x124>(dc.x); dc.y += dpp_row<0x124>(dc.y);
+    }
+    {
+        const int g = tid / C::G, c = tid % C::G;
+        if (c < W) {
+            l_red[g][c] = acc;
+            if (c == 0) l_dc[g] = dc;
+        }
+    }
+    lds_barrier();
+    float2 *slab = a.part + ((size_t) s * PS + ps) * M;
+    if (tid < W) {
+        float4 t = l_red[0][tid];
+        float2 d = l_dc[0];
+#pragma unroll
+        for (int g = 1; g < C::NP; g++) {
+            const float4 v = l_red[g][tid];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            d.x += l_dc[g].x; d.y += l_dc[g].y;
+        }
+        const int b = 2 * (cs * W + tid);
+        const float2 lo = b == 0 ? d : make_float2(t.x, t.y);       // packed bin 0: two real products
+        const float2 hi = make_float2(t.z, t.w);
+        if constexpr (SC1) { st_sc1(slab + b, lo); st_sc1(slab + b + 1, hi); }
+        else *reinterpret_cast<float4 *>(slab + b) = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+
+    // ---- publish: drained stores, barrier, (plain-store form: one agent-scope release), one ticket ----
+    const unsigned total = (unsigned) (CS * PS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if constexpr (!SC1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        l_ticket = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (l_ticket != total - 1) return;
+
+    // ---- last arriver of this stream: sum the PS slabs, inverse FFT, overlap-add ----
+    if (tid == 0) {
+        if constexpr (!SC1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(&tickets[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (!SC1) __syncthreads();
+    const float2 *rows = a.part + (size_t) s * PS * M;
+    for (int b = tid; b < M; b += kThreads) {
+        float2 v = make_float2(0.f, 0.f);
+        int r = 0;
+        for (; r + 3 < PS; r += 4) {                   // four loads in flight
+            float2 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                w[i] = SC1 ? ld_sc1(rows + (size_t) (r + i) * M + b) : rows[(size_t) (r + i) * M + b];
+            v.x += (w[0].x + w[1].x) + (w[2].x + w[3].x);
+            v.y += (w[0].y + w[1].y) + (w[2].y + w[3].y);
+        }
+        for (; r < PS; r++) v = cadd(v, SC1 ? ld_sc1(rows + (size_t) r * M + b) : rows[(size_t) r * M + b]);
+        l_buf[b] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        wave_split_inverse<M>(l_buf, l_tw, lane);
+        wave_fft<M, true>(l_buf, l_tw, lane);
+        wave_overlap_add(reinterpret_cast<const float *>(l_buf), 1.0f / (float) N, a.B,
+                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Time-tiled path: a call that carries T > 1 new blocks per stream (host blocks larger than B, or the
 // whole signal in the offline function).  All T input spectra are pushed first, then every output
 //   Y_{j}[b] = sum_k X_{t0+j-k}[b] * H_k[b],  j = 0..T-1
@@ -622,15 +884,6 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     if (slot >= a.R) slot -= a.R;
     float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
     wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
-}
-
-// XCD-aware workgroup id: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
-// its own 4 MiB L2); this bijection gives every XCD one contiguous range of ids instead, so workgroups
-// that share X/H rows (neighbouring time tiles) also share an L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_contiguous_id(int bid, int nwg)
-{
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
 __device__ __forceinline__ int ring_slot(int head, int d, int R)

@@ -46,6 +46,27 @@ def single(B=256, Lh=96000, n=2000, flags=0):
     print(f"single stream B={B} Lh={Lh} splits={eng.info.splits}: device {ms/n*1e3:.2f} us/block, host-inclusive {wall/n*1e6:.2f} us/block")
 
 
+def few(I=1, C=2, B=128, Lh=480000, n=2000, flags=0):
+    """few streams, one block per call, device-resident: the latency path (configs[2] by default)"""
+    eng = FdlEngine(I, C, B, Lh, max_blocks_per_call=1, flags=flags)
+    for i in range(I):
+        eng.set_ir(i, np.stack([decaying_ir(1 + 2 * i + c, Lh) for c in range(C)]))
+    d_in, d_out, stride = eng.device_io()
+    eng.upload(d_in, np.stack([white_noise(5 + s, B) for s in range(I * C)]))
+    for _ in range(20):
+        eng.process_device(d_in, d_out, stride, 1)
+    eng.synchronize()
+    eng.mark(0)
+    for _ in range(n):
+        eng.process_device(d_in, d_out, stride, 1)
+    eng.mark(1)
+    ms = eng.elapsed_ms()
+    alg = I * C * eng.info.algorithmic_bytes_per_block_step
+    env = {k: v for k, v in os.environ.items() if k.startswith("IRB_")}
+    print(f"few I={I} C={C} B={B} Lh={Lh} P={eng.info.partitions} wgs/stream={eng.info.splits} flags={flags} {env}: "
+          f"{ms/n*1e3:.2f} us/step  {I*C*B/(ms/n)/1e3:.1f} Msamples/s  {alg/(ms/n)/1e6:.0f} GB/s algorithmic")
+
+
 def stereo(I=1024, B=256, Lh=96000, flags=0):
     """stereo instances with a mono IR (the plug-in's real-time layout), one block per call"""
     eng = FdlEngine(I, 2, B, Lh, max_blocks_per_call=1, flags=flags)
@@ -141,4 +162,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi, "few": few}[mode](*args)
