@@ -86,7 +86,7 @@ template <int MX, bool INV, bool COLS, bool SETUP = false>
 int launch_tile(irb_lfft *p, const irb::LfftArgs &a, const float2 *src, float2 *dst, int nwg)
 {
     const int R = p->tile_rows;
-    const size_t lds = sizeof(float2) * ((size_t) R * (MX + 1) + MX);
+    const size_t lds = sizeof(float2) * ((size_t) R * (MX + 1) + irb::TwLds<2 * MX>::SIZE);
     if (R == 16 && MX <= 1024) {
         auto k = irb::k_lfft_tile<MX, 16, INV, COLS>;
         if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }

@@ -57,6 +57,7 @@ struct irb_fdl {
     bool nt = false;                         // non-temporal row loads in the fused kernel
     int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
                                              // `splits` then counts partition splits (workgroups per stream = CS * splits)
+    bool fused_deep = false;                 // fused kernel with 8 partitions per stripe in flight (one workgroup per CU)
     bool cols_sc1 = true;                    // its hand-off: write-through slices (grid <= one workgroup per CU) or fences
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
@@ -126,29 +127,32 @@ void choose_path(irb_fdl *h)
         h->splits = env_int("IRB_SPLITS", sp < 2 ? 1 : sp);
         return;
     }
-    // from two workgroups per CU on, the fused kernel runs at its HBM rate and needs no hand-off at all
-    if (!force_cols && h->S >= env_int("IRB_FUSED_FROM", 512)) return;
-    // column slice width: the narrowest of {4, 16, 64} float4 that keeps S * CS within one workgroup per CU; a
-    // 4-column slice is one 64-byte piece per row, a 64-column slice one fully coalesced KiB per wave
+    // Measured on MI355X (profiles/r02_latency_sweep.txt, r02_batch_sweep.txt, r02_step_stamps.txt):
+    //  * from 256 streams on, one workgroup per stream fills the chip and needs no hand-off: fused kernel;
+    //  * short IRs: the hand-off (~2 us: drained write-through store, ticket, slice loads) costs more than streaming
+    //    the few rows in one workgroup (fused ~ 5.7 us + 0.05 us per 2-KiB partition row);
+    //  * otherwise column slices x partition splits with <= 256 workgroups (a second workgroup per CU only queues
+    //    behind the first on this latency-bound path), two rounds of loads per thread for long IRs (more splits
+    //    shorten the loads but every workgroup adds ~13 ns to the stream's ticket counter and a row to the final sum).
+    if (!force_cols && (h->S >= env_int("IRB_FUSED_FROM", 256) || (long) h->P * h->N <= env_int("IRB_FUSED_ROWS", 48) * 512L)) return;
     int W = 64;
     for (int w : {4, 16, 64}) {
         const int we = std::min(w, L);
-        if ((long) h->S * (L / we) <= 256) { W = w; break; }
+        if ((long) h->S * (L / we) <= 64) { W = w; break; }
     }
     W = env_int("IRB_COLW", W);
     if (W != 4 && W != 16 && W != 64) W = 64;
     const int we = std::min(W, L), CS = L / we, NS = irb::kThreads / we;
     const long base = (long) h->S * CS;
-    // partition splits: fill the chip (latency regime: one workgroup per CU; batches: ~4 per CU), but leave every
-    // thread at least 4 partitions, and never more splits than the last arriver can sum in one round of loads
-    const int by_work = std::max(1, h->P / (NS * 4));
-    const long target = base <= 256 ? 256 : 1024;
-    int PS = (int) std::max<long>(1, std::min<long>(std::min(by_work, 16), target / base));
+    const int per_two_rounds = 2 * NS * 8;                                    // ColsGeom::U = 8 partitions per thread per round
+    int PS = (h->P + per_two_rounds - 1) / per_two_rounds;
+    PS = (int) std::min<long>(PS, std::max<long>(1, 256 / base));
+    PS = std::max(1, std::min(PS, 16));
     PS = std::max(1, env_int("IRB_PSPLITS", PS));
     h->colW = W;
     h->splits = PS;
-    // write-through hand-off is measured for one workgroup per CU; larger grids use the release/acquire form
-    h->cols_sc1 = env_int("IRB_COLS_SC1", base * PS <= 256 ? 1 : 0) != 0;
+    // write-through (sc1) slices: no release/acquire fence.  IRB_COLS_SC1=0 selects the fenced form (A/B, tests).
+    h->cols_sc1 = env_int("IRB_COLS_SC1", 1) != 0;
 }
 
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
@@ -203,6 +207,7 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
             else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         }
         else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else if (h->fused_deep) { FOR_N(h->N, irb::k_step_fused<NN, 8, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
         FOR_N(h->N, irb::k_step_split<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets));
@@ -313,6 +318,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
     h->tiled1 = h->nt;
+    h->fused_deep = env_int("IRB_FUSED_DEEP", 0) != 0;
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
     if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
 

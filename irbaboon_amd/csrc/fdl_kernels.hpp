@@ -26,7 +26,18 @@ constexpr int kThreads = 256;
 // transforms per workgroup in the FFT-only kernels (one wave each); LDS = NF*M*8 + N*4 bytes
 template <int N> struct FftGeom { static constexpr int NF = N <= 2048 ? 4 : 2; };
 
+// Diagnostic builds only (tools/step_stamps.hip compiles this header with -DIRB_STAMPS; libirbfdl.so never does):
+// s_memtime stamps of the step kernels' phases, written to a buffer of their own by thread 0 of every workgroup.
+#ifdef IRB_STAMPS
+#define IRB_STAMP(a, i) irb::stamp_((a).stamps, (i))
+#else
+#define IRB_STAMP(a, i) do { } while (0)
+#endif
+
 struct StepArgs {
+#ifdef IRB_STAMPS
+    unsigned long long *stamps; // [grid][16]
+#endif
     const float2 *H;            // [n_sets][P][M]  (P here = allocated rows per set, a multiple of 8)
     float2       *X;            // [S][R][M]
     float        *ovl;          // [S][B]
@@ -43,6 +54,17 @@ struct StepArgs {
     int           T, nq;        // blocks in this call; partial rows per output (splits * stripes)
 };
 
+#ifdef IRB_STAMPS
+__device__ __forceinline__ void stamp_(unsigned long long *buf, int i)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + i] = t;
+}
+#endif
+
 // Overlap-add (reference fp/convolution.cpp:209-213) by one wave: y = N real samples, unscaled, in LDS.
 __device__ __forceinline__ void wave_overlap_add(const float *y, float scale, int B, float *__restrict__ ovl,
                                                  float *__restrict__ out, int lane)
@@ -53,6 +75,52 @@ __device__ __forceinline__ void wave_overlap_add(const float *y, float scale, in
         out[i] = o;
     }
 }
+
+// One wave's share of a block step's audio I/O, kept in registers across the multiply-accumulate: XL samples per
+// lane of the new block (sample lane + 64 i) and of the overlap saved by the previous step.  Loads are clamped,
+// not predicated (a predicated load makes hipcc wait for it at the join); the padding is applied on use.
+template <int N>
+struct BlockIo {
+    static constexpr int M = N / 2;
+    static constexpr int XL = M >= kWave ? M / kWave : 1;        // B <= M
+    float x[XL], ov[XL];
+
+    __device__ __forceinline__ void load(const float *__restrict__ xin, const float *__restrict__ ovl, int B, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int n = min(lane + i * kWave, B - 1);
+            x[i] = xin[n];
+            ov[i] = ovl[n];
+        }
+    }
+    // the block, zero padded to N reals, as the M-point complex input z[n] = x[2n] + i x[2n+1] (same memory)
+    __device__ __forceinline__ void block_to_lds(float2 *buf, int B, int lane) const
+    {
+        float *zf = reinterpret_cast<float *>(buf);
+#pragma unroll
+        for (int i = 0; i < N / kWave; i++) {
+            const int n = lane + i * kWave;
+            if (i < XL) zf[n] = n < B ? x[i] : 0.0f;
+            else zf[n] = 0.0f;
+        }
+        if constexpr (N < kWave) { if (lane < N) zf[lane] = lane < B ? x[0] : 0.0f; }
+    }
+    // overlap-add (reference fp/convolution.cpp:209-213): y = N real samples, unscaled, in LDS
+    __device__ __forceinline__ void overlap_add(const float2 *buf, int B, float *__restrict__ ovl, float *__restrict__ out, int lane) const
+    {
+        const float *y = reinterpret_cast<const float *>(buf);
+        const float scale = 1.0f / (float) N;
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int n = lane + i * kWave;
+            if (n < B) {
+                out[n] = y[n] * scale + ov[i];
+                ovl[n] = y[B + n] * scale;
+            }
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Multiply-accumulate over partitions [kb, ke) of one stream (reference fp/convolution.cpp:171-202):
@@ -160,7 +228,7 @@ __device__ __forceinline__ void reduce_stripes(const float4 (&acc)[MacGeom<N>::C
 template <int N>
 struct Lds {
     static constexpr int M = N / 2;
-    float2 tw[N / 2];                              // half twiddle table
+    float2 tw[TwLds<N>::SIZE];                     // twiddle table W_N^j, j < 3N/4
     float2 buf[M];                                 // wave 0's FFT buffer; later the summed spectrum Y
     float2 scratch[MacGeom<N>::STRIPES * M];       // first the new block's spectrum, then the stripe partials
 };
@@ -185,25 +253,15 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
 
+    IRB_STAMP(a, 0);
     // issue the small loads now (twiddle half table, and wave 0: the new block) so that their latency
     // hides under the partition stream; they are parked in registers until the MAC loop is done
     constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
-    constexpr int ZPL = M > kWave ? M / kWave : 1;
     float2 twr[TWPT];
 #pragma unroll
-    for (int i = 0; i < TWPT; i++) {
-        const int idx = threadIdx.x + i * kThreads;
-        twr[i] = idx < N / 2 ? a.tw[idx] : make_float2(0.f, 0.f);
-    }
-    float2 zr[ZPL];
-    if (wave == 0) {
-        const float *x = a.in + (size_t) s * a.in_stride;
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = 2 * (lane + i * kWave);
-            zr[i] = make_float2(n < a.B ? x[n] : 0.0f, n + 1 < a.B ? x[n + 1] : 0.0f);
-        }
-    }
+    for (int i = 0; i < TWPT; i++) twr[i] = a.tw[min((int) threadIdx.x + i * kThreads, N / 2 - 1)];
+    BlockIo<N> io;
+    if (wave == 0) io.load(a.in + (size_t) s * a.in_stride, a.ovl + (size_t) s * a.B, a.B, lane);
 
     // older partitions: their rows do not depend on the new block
     float4 acc[G::CPT];
@@ -211,26 +269,24 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
     for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
     mac_range<N, U, NT>(H4, X4, 1, np, a.head, a.R, acc, dc);
+    IRB_STAMP(a, 1);
 
 #pragma unroll
     for (int i = 0; i < TWPT; i++) {
         const int idx = threadIdx.x + i * kThreads;
-        if (idx < N / 2) lds.tw[idx] = twr[i];
+        if (idx < N / 2) put_twiddle<N>(lds.tw, idx, twr[i]);
     }
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = lane + i * kWave;
-            if (n < M) lds.buf[n] = zr[i];
-        }
-    }
+    if (wave == 0) io.block_to_lds(lds.buf, a.B, lane);
     __syncthreads();
+    IRB_STAMP(a, 2);
     if (wave == 0) {      // new block: FFT, packed spectrum to LDS (for partition 0) and into the ring
         wave_fft<M, false>(lds.buf, lds.tw, lane);
+        IRB_STAMP(a, 3);
         float2 *ring = Xs + (size_t) a.head * M;
         wave_split_forward<M>(lds.buf, lds.tw, lane, [&](int b, float2 v) { lds.scratch[b] = v; ring[b] = v; });
     }
     __syncthreads();
+    IRB_STAMP(a, 4);
 
     if (np > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
         const int col = threadIdx.x;
@@ -246,13 +302,21 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
         }
     }
     __syncthreads();
+    IRB_STAMP(a, 5);
 
     reduce_stripes<N>(acc, dc, lds.scratch, lds.buf);
+    IRB_STAMP(a, 6);
     if (wave == 0) {
         wave_split_inverse<M>(lds.buf, lds.tw, lane);
+        IRB_STAMP(a, 7);
         wave_fft<M, true>(lds.buf, lds.tw, lane);
-        wave_overlap_add(reinterpret_cast<const float *>(lds.buf), 1.0f / (float) N, a.B,
-                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+        IRB_STAMP(a, 8);
+        io.overlap_add(lds.buf, a.B, a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+        IRB_STAMP(a, 9);
+#ifdef IRB_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IRB_STAMP(a, 10);
+#endif
     }
 }
 
@@ -266,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
 template <int N>
 struct LdsPair {
     static constexpr int M = N / 2;
-    float2 tw[N / 2];
+    float2 tw[TwLds<N>::SIZE];
     float2 buf[2][M];
     float2 scratch[2][MacGeom<N>::STRIPES * M];
 };
@@ -296,22 +360,11 @@ __global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
     const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
 
     constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
-    constexpr int ZPL = M > kWave ? M / kWave : 1;
     float2 twr[TWPT];
 #pragma unroll
-    for (int i = 0; i < TWPT; i++) {
-        const int idx = threadIdx.x + i * kThreads;
-        twr[i] = idx < N / 2 ? a.tw[idx] : make_float2(0.f, 0.f);
-    }
-    float2 zr[ZPL];
-    if (wave < 2) {
-        const float *x = a.in + (size_t) (s0 + wave) * a.in_stride;
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = 2 * (lane + i * kWave);
-            zr[i] = make_float2(n < a.B ? x[n] : 0.0f, n + 1 < a.B ? x[n + 1] : 0.0f);
-        }
-    }
+    for (int i = 0; i < TWPT; i++) twr[i] = a.tw[min((int) threadIdx.x + i * kThreads, N / 2 - 1)];
+    BlockIo<N> io;
+    if (wave < 2) io.load(a.in + (size_t) (s0 + wave) * a.in_stride, a.ovl + (size_t) (s0 + wave) * a.B, a.B, lane);
 
     float4 acc[2][G::CPT];
     float2 dc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
@@ -354,15 +407,9 @@ __global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
 #pragma unroll
     for (int i = 0; i < TWPT; i++) {
         const int idx = threadIdx.x + i * kThreads;
-        if (idx < N / 2) lds.tw[idx] = twr[i];
+        if (idx < N / 2) put_twiddle<N>(lds.tw, idx, twr[i]);
     }
-    if (wave < 2) {
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = lane + i * kWave;
-            if (n < M) lds.buf[wave][n] = zr[i];
-        }
-    }
+    if (wave < 2) io.block_to_lds(lds.buf[wave], a.B, lane);
     __syncthreads();
     if (wave < 2) {       // new blocks: FFT, spectrum to LDS (for partition 0) and into the ring
         wave_fft<M, false>(lds.buf[wave], lds.tw, lane);
@@ -385,8 +432,7 @@ __global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
     if (wave < 2) {
         wave_split_inverse<M>(lds.buf[wave], lds.tw, lane);
         wave_fft<M, true>(lds.buf[wave], lds.tw, lane);
-        wave_overlap_add(reinterpret_cast<const float *>(lds.buf[wave]), 1.0f / (float) N, a.B,
-                         a.ovl + (size_t) (s0 + wave) * a.B, a.out + (size_t) (s0 + wave) * a.out_stride, lane);
+        io.overlap_add(lds.buf[wave], a.B, a.ovl + (size_t) (s0 + wave) * a.B, a.out + (size_t) (s0 + wave) * a.out_stride, lane);
     }
 }
 
@@ -401,7 +447,7 @@ template <int N>
 __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft(StepArgs a, int S)
 {
     constexpr int M = N / 2, NF = FftGeom<N>::NF;
-    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int s = blockIdx.x * NF + wave;
@@ -482,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2;
-    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[M];
     __shared__ float2 l_part[G::STRIPES * M];
     const int s = blockIdx.x;
@@ -642,14 +688,22 @@ __device__ __forceinline__ float2 ld_sc1(const float2 *p)
     return v;
 }
 
+// lane-wise sum over the four 16-lane rows of a wave (v_permlane16_swap / v_permlane32_swap, gfx950): every lane
+// ends up with the sum of the lanes that share its position in the row
+__device__ __forceinline__ float rows_sum(float v)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int N, int W_>
 struct ColsGeom {
     static constexpr int M = N / 2, L = M / 2;
     static constexpr int W = W_ < L ? W_ : L;                   // float4 columns per slice
     static constexpr int CS = L / W;                            // column slices per row
     static constexpr int NS = kThreads / W;                     // stripes (partitions in flight per load slot)
-    static constexpr int G = W < 16 ? 16 : W;                   // threads that end up holding one partial row
-    static constexpr int NP = kThreads / G;                     // partial rows combined through LDS
     static constexpr int U = 8;                                 // partitions per thread per round
 };
 
@@ -657,12 +711,12 @@ template <int N, int W_, bool SC1>
 __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__restrict__ tickets)
 {
     using C = ColsGeom<N, W_>;
-    constexpr int M = C::M, W = C::W, CS = C::CS, NS = C::NS, U = C::U;
-    __shared__ float2 l_tw[N / 2];
+    constexpr int M = C::M, W = C::W, CS = C::CS, NS = C::NS, U = C::U, NWAVES = kThreads / kWave;
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[M];                        // FFT work buffer; later the summed spectrum
     __shared__ float2 l_spec[M];                       // packed spectrum of the new block
-    __shared__ float4 l_red[C::NP][W];
-    __shared__ float2 l_dc[C::NP];
+    __shared__ float4 l_red[NWAVES][W];
+    __shared__ float2 l_dc[NWAVES];
     __shared__ unsigned l_ticket;
     const int PS = a.splits;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // neighbouring column slices share an XCD's L2
@@ -677,33 +731,26 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
     const bool first = (ps == 0);                      // this workgroup also owns partition 0 of its columns
+    IRB_STAMP(a, 0);
 
-    // ---- small loads first (they complete first): twiddles, the new block, H row 0.  All UNCONDITIONAL (clamped
-    // addresses, the zero padding is applied when the values are used): a predicated load makes hipcc wait for it
-    // at the join, in front of the partition loads ----
+    // ---- small loads first (they complete first): twiddles, H row 0, and in wave 0 the new block and the saved
+    // overlap (whichever workgroup arrives last will need it: prefetched everywhere, B floats).  Unconditional per
+    // lane (clamped addresses, the padding is applied when the values are used): a lane-predicated load makes hipcc
+    // wait for it at the join, in front of the partition loads ----
     constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
-    constexpr int ZPL = M > kWave ? M / kWave : 1;
     float2 twr[TWPT];
 #pragma unroll
     for (int i = 0; i < TWPT; i++) twr[i] = a.tw[min(tid + i * kThreads, N / 2 - 1)];
-    float zre[ZPL], zim[ZPL];
-    {
-        const float *xin = a.in + (size_t) s * a.in_stride;
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = 2 * (lane + i * kWave);
-            zre[i] = xin[min(n, a.B - 1)];
-            zim[i] = xin[min(n + 1, a.B - 1)];
-        }
-    }
+    BlockIo<N> io;
+    if (wave == 0) io.load(a.in + (size_t) s * a.in_stride, a.ovl + (size_t) s * a.B, a.B, lane);
     const float4 h0 = H4[gcol];                        // row 0 always exists (used only when np > 0)
 
-    // ---- the partition loads of this thread: one round covers NS*U partitions of the range ----
+    // ---- the partition loads of this thread: one round covers NS*U partitions of the range.  Unconditional too
+    // (a slot past the range re-reads a row this wave has just asked for and is masked when it is used): with
+    // branch-free issue hipcc counts vmcnt exactly, so the FFT below starts when the SMALL loads have landed
+    // while these are still in flight ----
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
-    // Loads are unconditional (a slot past the range re-reads a row this wave has just asked for and is masked when
-    // it is used): with branch-free issue hipcc counts vmcnt exactly, so the FFT below starts when the SMALL loads
-    // have landed while these are still in flight.
     float4 h[U], x[U];
     int k = kb + stripe;
     auto issue = [&](int k0) {
@@ -732,27 +779,25 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     };
     issue(k);
     __builtin_amdgcn_sched_barrier(0);                 // nothing that waits for a small load moves above the issue
+    IRB_STAMP(a, 1);
 
-    // ---- twiddles (and the block) to LDS; forward FFT by wave 0 while the partition loads are in flight ----
+    // ---- twiddles (and the block, zero padded to N reals) to LDS; forward FFT by wave 0 while the partition
+    // loads are in flight ----
 #pragma unroll
     for (int i = 0; i < TWPT; i++) {
         const int idx = tid + i * kThreads;
-        if (idx < N / 2) l_tw[idx] = twr[i];
+        if (idx < N / 2) put_twiddle<N>(l_tw, idx, twr[i]);
     }
-    if (first && wave == 0) {
-#pragma unroll
-        for (int i = 0; i < ZPL; i++) {
-            const int n = lane + i * kWave;
-            if (n < M) l_buf[n] = make_float2(2 * n < a.B ? zre[i] : 0.0f, 2 * n + 1 < a.B ? zim[i] : 0.0f);
-        }
-    }
+    if (first && wave == 0) io.block_to_lds(l_buf, a.B, lane);
     lds_barrier();
+    IRB_STAMP(a, 2);
     if (first) {
         if (wave == 0) {
             wave_fft<M, false>(l_buf, l_tw, lane);
             wave_split_forward<M>(l_buf, l_tw, lane, [&](int b, float2 v) { l_spec[b] = v; });
         }
         lds_barrier();
+        IRB_STAMP(a, 3);
         if (stripe == 0) {                             // partition 0 of this slice; the slice also goes into the ring
             const float4 x0 = reinterpret_cast<const float4 *>(l_spec)[gcol];
             reinterpret_cast<float4 *>(Xs + (size_t) a.head * M)[gcol] = x0;
@@ -767,12 +812,14 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         }
     }
     consume(k);
-    for (k += NS * U; k < ke; k += NS * U) {           // ranges longer than one round (long IRs, few splits)
+    for (k += NS * U; k < ke; k += NS * U) {           // ranges longer than two rounds' worth (few splits)
         issue(k);
         consume(k);
     }
+    IRB_STAMP(a, 4);
 
-    // ---- combine the stripes: DPP rotations inside rows of 16 lanes, then NP partial rows through LDS ----
+    // ---- combine the stripes: inside a wave by lane permutes (DPP rotations within rows of 16 lanes, permlane
+    // swaps across the rows), then the four waves through LDS ----
     if constexpr (W <= 8) {
         acc.x += dpp_row<0x128>(acc.x); acc.y += dpp_row<0x128>(acc.y); acc.z += dpp_row<0x128>(acc.z); acc.w += dpp_row<0x128>(acc.w);
         dc.x += dpp_row<0x128>(dc.x); dc.y += dpp_row<0x128>(dc.y);
@@ -781,12 +828,19 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         acc.x += dpp_row<0x124>(acc.x); acc.y += dpp_row<0x124>(acc.y); acc.z += dpp_row<0x124>(acc.z); acc.w += dpp_row<0x124>(acc.w);
         dc.x += dpp_row<0x124>(dc.x); dc.y += dpp_row<0x124>(dc.y);
     }
-    {
-        const int g = tid / C::G, c = tid % C::G;
-        if (c < W) {
-            l_red[g][c] = acc;
-            if (c == 0) l_dc[g] = dc;
-        }
+    if constexpr (W <= 16) {
+        acc.x = rows_sum(acc.x); acc.y = rows_sum(acc.y); acc.z = rows_sum(acc.z); acc.w = rows_sum(acc.w);
+        dc.x = rows_sum(dc.x); dc.y = rows_sum(dc.y);
+    } else if constexpr (W == 32) {
+        const auto sw = [](float v) {
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        };
+        acc.x = sw(acc.x); acc.y = sw(acc.y); acc.z = sw(acc.z); acc.w = sw(acc.w); dc.x = sw(dc.x); dc.y = sw(dc.y);
+    }
+    if (lane < W) {                                    // W <= 64: lane == column
+        l_red[wave][lane] = acc;
+        if (lane == 0) l_dc[wave] = dc;
     }
     lds_barrier();
     float2 *slab = a.part + ((size_t) s * PS + ps) * M;
@@ -794,7 +848,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         float4 t = l_red[0][tid];
         float2 d = l_dc[0];
 #pragma unroll
-        for (int g = 1; g < C::NP; g++) {
+        for (int g = 1; g < NWAVES; g++) {
             const float4 v = l_red[g][tid];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
             d.x += l_dc[g].x; d.y += l_dc[g].y;
@@ -808,8 +862,10 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
 
     // ---- publish: drained stores, barrier, (plain-store form: one agent-scope release), one ticket ----
     const unsigned total = (unsigned) (CS * PS);
+    IRB_STAMP(a, 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    IRB_STAMP(a, 6);
     if (tid == 0) {
         if constexpr (!SC1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -818,6 +874,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         l_ticket = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    IRB_STAMP(a, 7);
     if (l_ticket != total - 1) return;
 
     // ---- last arriver of this stream: sum the PS slabs, inverse FFT, overlap-add ----
@@ -845,11 +902,16 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         l_buf[b] = v;
     }
     __syncthreads();
+    IRB_STAMP(a, 8);
     if (wave == 0) {
         wave_split_inverse<M>(l_buf, l_tw, lane);
         wave_fft<M, true>(l_buf, l_tw, lane);
-        wave_overlap_add(reinterpret_cast<const float *>(l_buf), 1.0f / (float) N, a.B,
-                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+        IRB_STAMP(a, 9);
+        io.overlap_add(l_buf, a.B, a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);   // overlap prefetched at the top
+#ifdef IRB_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IRB_STAMP(a, 10);
+#endif
     }
 }
 
@@ -869,7 +931,7 @@ template <int N>
 __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepArgs a, int S)
 {
     constexpr int M = N / 2, NF = FftGeom<N>::NF;
-    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int item = blockIdx.x * NF + wave;
@@ -1062,7 +1124,7 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ifft_ola_batch(StepA
 {
     constexpr int M = N / 2, NF = FftGeom<N>::NF;
     constexpr int VPL = M > kWave ? M / kWave : 1;     // tail samples per lane (B <= M)
-    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int item = blockIdx.x * NF + wave;
@@ -1117,7 +1179,7 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *
                                                                    int first_partition, int nparts, int nrows)
 {
     constexpr int M = N / 2, NF = FftGeom<N>::NF;
-    __shared__ float2 l_tw[N / 2];
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int item = blockIdx.x * NF + wave;

@@ -38,14 +38,14 @@ template <int M1, bool INV>
 __global__ __launch_bounds__(kWave * WaveGeom<M1>::NF) void k_lfft_cols(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
 {
     constexpr int NF = WaveGeom<M1>::NF;
-    __shared__ float2 l_tw[M1];
+    __shared__ float2 l_tw[TwLds<2 * M1>::SIZE];
     __shared__ float2 l_buf[NF][M1];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const long item = (long) blockIdx.x * NF + wave;
     const bool live = item < (long) a.batch * a.M2;
     const int n2 = (int) (item % a.M2);
     const long b = item / a.M2;
-    for (int i = threadIdx.x; i < M1; i += blockDim.x) l_tw[i] = a.tw1[i];
+    for (int i = threadIdx.x; i < M1; i += blockDim.x) put_twiddle<2 * M1>(l_tw, i, a.tw1[i]);
     if (live) {
         const float2 *src = in + b * a.M + n2;
         for (int n1 = lane; n1 < M1; n1 += kWave) l_buf[wave][n1] = src[(size_t) n1 * a.M2];
@@ -66,14 +66,14 @@ template <int M2, bool INV>
 __global__ __launch_bounds__(kWave * WaveGeom<M2>::NF) void k_lfft_rows(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
 {
     constexpr int NF = WaveGeom<M2>::NF;
-    __shared__ float2 l_tw[M2];
+    __shared__ float2 l_tw[TwLds<2 * M2>::SIZE];
     __shared__ float2 l_buf[NF][M2];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const long item = (long) blockIdx.x * NF + wave;
     const bool live = item < (long) a.batch * a.M1;
     const int k1 = (int) (item % a.M1);
     const long b = item / a.M1;
-    for (int i = threadIdx.x; i < M2; i += blockDim.x) l_tw[i] = a.tw2[i];
+    for (int i = threadIdx.x; i < M2; i += blockDim.x) put_twiddle<2 * M2>(l_tw, i, a.tw2[i]);
     if (live) {
         const float2 *src = in + b * a.M + (size_t) k1 * M2;
         for (int n2 = lane; n2 < M2; n2 += kWave) l_buf[wave][n2] = src[n2];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kWave * WaveGeom<M2>::NF) void k_lfft_rows(LfftArgs
 // ---- tiled passes: R adjacent columns (pass 1) / rows (pass 2) per workgroup, one wave each, with the global
 // traffic staged through a padded LDS tile so that every global access is an R*8-byte contiguous piece
 // (the one-wave-per-item kernels above touch 8 bytes per 4-KiB stride in one of their two phases).
-// Dynamic LDS: R*(MX+1) + MX float2.
+// Dynamic LDS: R*(MX+1) + 3*MX/2 float2 (tile + the wave FFT's twiddle table).
 template <int MX, int R, bool INV, bool COLS>
 __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
 {
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     constexpr int LD = MX + 1;                               // padded row: transposed accesses spread over banks
     constexpr int NT = kWave * R;
     float2 *tile = reinterpret_cast<float2 *>(l_raw);        // [R][LD]
-    float2 *l_tw = tile + R * LD;                            // [MX]
+    float2 *l_tw = tile + R * LD;                            // [TwLds<2*MX>::SIZE]
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int other = COLS ? a.M2 : a.M1;                    // length of the dimension the groups run along
     const int groups = other / R;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     const int i0 = g * R;                                    // first column n2 (COLS) / first row k1 (rows)
     const float2 *src = in + b * a.M;
     float2 *dst = out + b * a.M;
-    for (int i = threadIdx.x; i < MX; i += NT) l_tw[i] = COLS ? a.tw1[i] : a.tw2[i];
+    for (int i = threadIdx.x; i < MX; i += NT) put_twiddle<2 * MX>(l_tw, i, COLS ? a.tw1[i] : a.tw2[i]);
     if (COLS) {
         for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // x[n1*M2 + n2]: R contiguous n2 per n1
             const int n1 = idx / R, r = idx % R;
@@ -150,12 +150,12 @@ template <int M, bool INV>
 __global__ __launch_bounds__(kWave * WaveGeom<M>::NF) void k_lfft_small(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
 {
     constexpr int NF = WaveGeom<M>::NF;
-    __shared__ float2 l_tw[M];
+    __shared__ float2 l_tw[TwLds<2 * M>::SIZE];
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const long b = (long) blockIdx.x * NF + wave;
     const bool live = b < a.batch;
-    for (int i = threadIdx.x; i < M; i += blockDim.x) l_tw[i] = a.tw1[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) put_twiddle<2 * M>(l_tw, i, a.tw1[i]);
     if (live)
         for (int n = lane; n < M; n += kWave) l_buf[wave][n] = in[b * M + n];
     __syncthreads();
