@@ -142,9 +142,11 @@ void choose_path(irb_fdl *h)
     }
     W = env_int("IRB_COLW", W);
     if (W != 4 && W != 16 && W != 64) W = 64;
-    const int we = std::min(W, L), CS = L / we, NS = irb::kThreads / we;
+    const int we = std::min(W, L), CS = L / we;
     const long base = (long) h->S * CS;
-    const int per_two_rounds = 2 * NS * 8;                                    // ColsGeom::U = 8 partitions per thread per round
+    // two rounds of loads per thread (8 rows of H and 8 of the FDL each): more splits shorten the loads, but every
+    // workgroup adds ~13 ns to the stream's ticket counter and a row to the last arriver's sum
+    const int per_two_rounds = 2 * (irb::kThreads / we) * 8;
     int PS = (h->P + per_two_rounds - 1) / per_two_rounds;
     PS = (int) std::min<long>(PS, std::max<long>(1, 256 / base));
     PS = std::max(1, std::min(PS, 16));

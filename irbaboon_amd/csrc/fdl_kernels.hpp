@@ -62,6 +62,11 @@ __device__ __forceinline__ void stamp_(unsigned long long *buf, int i)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + i] = t;
+    if (i == 0 || i == 7 || i == 10) {               // the 100 MHz reference clock too: comparable ACROSS workgroups / XCDs
+        unsigned long long r;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) :: "memory");
+        if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + (i == 0 ? 11 : i == 7 ? 12 : 13)] = r;
+    }
 }
 #endif
 
@@ -703,15 +708,23 @@ struct ColsGeom {
     static constexpr int M = N / 2, L = M / 2;
     static constexpr int W = W_ < L ? W_ : L;                   // float4 columns per slice
     static constexpr int CS = L / W;                            // column slices per row
-    static constexpr int NS = kThreads / W;                     // stripes (partitions in flight per load slot)
-    static constexpr int U = 8;                                 // partitions per thread per round
+    static constexpr int TWL = N / 2 >= kWave ? N / 2 / kWave : 1;   // host twiddle entries per lane of ONE wave
 };
 
-template <int N, int W_, bool SC1>
+// Roles inside a workgroup of k_step_cols:
+//   * wave 0 of a workgroup of partition range 0 ("FFT wave"): small loads only (twiddles, the new block, H row 0,
+//     the saved overlap), forward FFT + split of the new block, partition 0 of its columns, the slice of the new
+//     spectrum into the ring.  It issues no partition loads, so its FFT starts as soon as its 2-3 KiB have landed
+//     and runs while the other waves' loads are in flight (profiles/r02_step_stamps.txt: with every wave issuing
+//     partition loads first, the texture addresser kept the FFT waiting ~0.8 us).
+//   * every other wave ("loader"): its stripe of the partition range, U rows of H and of the FDL per thread per
+//     round, unconditional 16-byte loads; wave 0 of the other workgroups also stages the twiddles and prefetches
+//     the overlap, because ANY workgroup can turn out to be the last arriver that runs the inverse FFT.
+template <int N, int W_, bool SC1, int U = 8>
 __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__restrict__ tickets)
 {
     using C = ColsGeom<N, W_>;
-    constexpr int M = C::M, W = C::W, CS = C::CS, NS = C::NS, U = C::U, NWAVES = kThreads / kWave;
+    constexpr int M = C::M, W = C::W, CS = C::CS, TWL = C::TWL, NWAVES = kThreads / kWave;
     __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[M];                        // FFT work buffer; later the summed spectrum
     __shared__ float2 l_spec[M];                       // packed spectrum of the new block
@@ -722,123 +735,127 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // neighbouring column slices share an XCD's L2
     const int cs = wg % CS, ps = (wg / CS) % PS, s = wg / (CS * PS);
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const int col = tid % W, stripe = tid / W, gcol = cs * W + col;
     const int set = a.set_of_stream[s];
     const int np = a.np_of_set[set];
-    const int nold = np > 0 ? np - 1 : 0;              // partition 0 pairs with the block transformed in this launch
-    const int kb = 1 + (int) ((long) nold * ps / PS), ke = 1 + (int) ((long) nold * (ps + 1) / PS);
+    // partition 0 pairs with the block transformed in this launch and belongs to range 0; the older partitions
+    // [1, np) are divided in proportion to the loader waves: 3 in a workgroup of range 0, 4 in the others
+    const int nold = np > 0 ? np - 1 : 0;
+    const int wtot = 4 * PS - 1, w0 = ps == 0 ? 0 : 4 * ps - 1, w1 = 4 * ps + 3;
+    const int kb = 1 + (int) ((long) nold * w0 / wtot), ke = 1 + (int) ((long) nold * w1 / wtot);
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
     const bool first = (ps == 0);                      // this workgroup also owns partition 0 of its columns
+    const bool fft_wave = first && wave == 0;
     IRB_STAMP(a, 0);
 
-    // ---- small loads first (they complete first): twiddles, H row 0, and in wave 0 the new block and the saved
-    // overlap (whichever workgroup arrives last will need it: prefetched everywhere, B floats).  Unconditional per
-    // lane (clamped addresses, the padding is applied when the values are used): a lane-predicated load makes hipcc
-    // wait for it at the join, in front of the partition loads ----
-    constexpr int TWPT = (N / 2 + kThreads - 1) / kThreads;
-    float2 twr[TWPT];
-#pragma unroll
-    for (int i = 0; i < TWPT; i++) twr[i] = a.tw[min(tid + i * kThreads, N / 2 - 1)];
-    BlockIo<N> io;
-    if (wave == 0) io.load(a.in + (size_t) s * a.in_stride, a.ovl + (size_t) s * a.B, a.B, lane);
-    const float4 h0 = H4[gcol];                        // row 0 always exists (used only when np > 0)
-
-    // ---- the partition loads of this thread: one round covers NS*U partitions of the range.  Unconditional too
-    // (a slot past the range re-reads a row this wave has just asked for and is masked when it is used): with
-    // branch-free issue hipcc counts vmcnt exactly, so the FFT below starts when the SMALL loads have landed
-    // while these are still in flight ----
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 dc = make_float2(0.f, 0.f);
-    float4 h[U], x[U];
-    int k = kb + stripe;
-    auto issue = [&](int k0) {
-        const int kdup = k0 < ke ? k0 : 0;
+    BlockIo<N> io;                                     // wave 0: new block + saved overlap (prefetched: any workgroup may run the tail)
+    float2 twr[TWL];
+    if (wave == 0) {                                   // loads are clamped, never lane-predicated (see BlockIo)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int kk = k0 + u * NS < ke ? k0 + u * NS : kdup;
-            int slot = a.head - kk;
-            if (slot < 0) slot += a.R;
-            h[u] = H4[(size_t) kk * C::L + gcol];
-            x[u] = X4[(size_t) slot * C::L + gcol];
-        }
-    };
-    auto consume = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool live = k0 + u * NS < ke;
-            const float4 xv = live ? x[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-            dc.x += xv.x * h[u].x;
-            dc.y += xv.y * h[u].y;
-            acc.x += xv.x * h[u].x - xv.y * h[u].y;
-            acc.y += xv.x * h[u].y + xv.y * h[u].x;
-            acc.z += xv.z * h[u].z - xv.w * h[u].w;
-            acc.w += xv.z * h[u].w + xv.w * h[u].z;
-        }
-    };
-    issue(k);
-    __builtin_amdgcn_sched_barrier(0);                 // nothing that waits for a small load moves above the issue
-    IRB_STAMP(a, 1);
-
-    // ---- twiddles (and the block, zero padded to N reals) to LDS; forward FFT by wave 0 while the partition
-    // loads are in flight ----
-#pragma unroll
-    for (int i = 0; i < TWPT; i++) {
-        const int idx = tid + i * kThreads;
-        if (idx < N / 2) put_twiddle<N>(l_tw, idx, twr[i]);
+        for (int i = 0; i < TWL; i++) twr[i] = a.tw[min(lane + i * kWave, N / 2 - 1)];
+        io.load(a.in + (size_t) s * a.in_stride, a.ovl + (size_t) s * a.B, a.B, lane);
     }
-    if (first && wave == 0) io.block_to_lds(l_buf, a.B, lane);
-    lds_barrier();
-    IRB_STAMP(a, 2);
-    if (first) {
-        if (wave == 0) {
-            wave_fft<M, false>(l_buf, l_tw, lane);
-            wave_split_forward<M>(l_buf, l_tw, lane, [&](int b, float2 v) { l_spec[b] = v; });
+
+    if (fft_wave) {
+        const int gcol = cs * W + (lane < W ? lane : 0);
+        const float4 h0 = H4[gcol];                    // row 0 always exists (used only when np > 0)
+        IRB_STAMP(a, 1);
+#pragma unroll
+        for (int i = 0; i < TWL; i++) {
+            const int idx = lane + i * kWave;
+            if (idx < N / 2) put_twiddle<N>(l_tw, idx, twr[i]);
         }
-        lds_barrier();
+        io.block_to_lds(l_buf, a.B, lane);
+        wave_sync();
+        IRB_STAMP(a, 2);
+        wave_fft<M, false>(l_buf, l_tw, lane);
+        wave_split_forward<M>(l_buf, l_tw, lane, [&](int b, float2 v) { l_spec[b] = v; });
+        wave_sync();
         IRB_STAMP(a, 3);
-        if (stripe == 0) {                             // partition 0 of this slice; the slice also goes into the ring
+        if (lane < W) {                                // partition 0 of this slice; the slice also goes into the ring
             const float4 x0 = reinterpret_cast<const float4 *>(l_spec)[gcol];
             reinterpret_cast<float4 *>(Xs + (size_t) a.head * M)[gcol] = x0;
             if (np > 0) {
-                dc.x += x0.x * h0.x;
-                dc.y += x0.y * h0.y;
-                acc.x += x0.x * h0.x - x0.y * h0.y;
-                acc.y += x0.x * h0.y + x0.y * h0.x;
-                acc.z += x0.z * h0.z - x0.w * h0.w;
-                acc.w += x0.z * h0.w + x0.w * h0.z;
+                dc = make_float2(x0.x * h0.x, x0.y * h0.y);
+                acc.x = x0.x * h0.x - x0.y * h0.y;
+                acc.y = x0.x * h0.y + x0.y * h0.x;
+                acc.z = x0.z * h0.z - x0.w * h0.w;
+                acc.w = x0.z * h0.w + x0.w * h0.z;
             }
         }
-    }
-    consume(k);
-    for (k += NS * U; k < ke; k += NS * U) {           // ranges longer than two rounds' worth (few splits)
-        issue(k);
-        consume(k);
-    }
-    IRB_STAMP(a, 4);
-
-    // ---- combine the stripes: inside a wave by lane permutes (DPP rotations within rows of 16 lanes, permlane
-    // swaps across the rows), then the four waves through LDS ----
-    if constexpr (W <= 8) {
-        acc.x += dpp_row<0x128>(acc.x); acc.y += dpp_row<0x128>(acc.y); acc.z += dpp_row<0x128>(acc.z); acc.w += dpp_row<0x128>(acc.w);
-        dc.x += dpp_row<0x128>(dc.x); dc.y += dpp_row<0x128>(dc.y);
-    }
-    if constexpr (W <= 4) {
-        acc.x += dpp_row<0x124>(acc.x); acc.y += dpp_row<0x124>(acc.y); acc.z += dpp_row<0x124>(acc.z); acc.w += dpp_row<0x124>(acc.w);
-        dc.x += dpp_row<0x124>(dc.x); dc.y += dpp_row<0x124>(dc.y);
-    }
-    if constexpr (W <= 16) {
-        acc.x = rows_sum(acc.x); acc.y = rows_sum(acc.y); acc.z = rows_sum(acc.z); acc.w = rows_sum(acc.w);
-        dc.x = rows_sum(dc.x); dc.y = rows_sum(dc.y);
-    } else if constexpr (W == 32) {
-        const auto sw = [](float v) {
-            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-            return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        IRB_STAMP(a, 4);
+    } else {
+        // loader waves: (first workgroup: waves 1..3, else all four) x (W columns) -> NS stripes
+        const int ltid = first ? tid - kWave : tid;
+        const int NS = (first ? kThreads - kWave : kThreads) / W;
+        const int col = ltid % W, stripe = ltid / W, gcol = cs * W + col;
+        float4 h[U], x[U];
+        auto issue = [&](int k0) {
+            const int kdup = k0 < ke ? k0 : 0;         // a slot past the range re-reads a row just asked for; masked on use
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int kk = k0 + u * NS < ke ? k0 + u * NS : kdup;
+                int slot = a.head - kk;
+                if (slot < 0) slot += a.R;
+                h[u] = H4[(size_t) kk * C::L + gcol];
+                x[u] = X4[(size_t) slot * C::L + gcol];
+            }
         };
-        acc.x = sw(acc.x); acc.y = sw(acc.y); acc.z = sw(acc.z); acc.w = sw(acc.w); dc.x = sw(dc.x); dc.y = sw(dc.y);
+        auto consume = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool live = k0 + u * NS < ke;
+                const float4 xv = live ? x[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                dc.x += xv.x * h[u].x;
+                dc.y += xv.y * h[u].y;
+                acc.x += xv.x * h[u].x - xv.y * h[u].y;
+                acc.y += xv.x * h[u].y + xv.y * h[u].x;
+                acc.z += xv.z * h[u].z - xv.w * h[u].w;
+                acc.w += xv.z * h[u].w + xv.w * h[u].z;
+            }
+        };
+        int k = kb + stripe;
+        issue(k);
+        __builtin_amdgcn_sched_barrier(0);
+        IRB_STAMP(a, 1);
+        if (wave == 0) {                               // twiddles for a possible inverse FFT later (this wave's own use)
+#pragma unroll
+            for (int i = 0; i < TWL; i++) {
+                const int idx = lane + i * kWave;
+                if (idx < N / 2) put_twiddle<N>(l_tw, idx, twr[i]);
+            }
+        }
+        consume(k);
+        for (k += NS * U; k < ke; k += NS * U) {       // ranges longer than one round (few splits)
+            issue(k);
+            consume(k);
+        }
+        IRB_STAMP(a, 4);
+        // combine the stripes inside the wave by lane permutes: DPP rotations within rows of 16 lanes, permlane
+        // swaps across the rows; lanes < W end up with the wave's column sums
+        if constexpr (W <= 8) {
+            acc.x += dpp_row<0x128>(acc.x); acc.y += dpp_row<0x128>(acc.y); acc.z += dpp_row<0x128>(acc.z); acc.w += dpp_row<0x128>(acc.w);
+            dc.x += dpp_row<0x128>(dc.x); dc.y += dpp_row<0x128>(dc.y);
+        }
+        if constexpr (W <= 4) {
+            acc.x += dpp_row<0x124>(acc.x); acc.y += dpp_row<0x124>(acc.y); acc.z += dpp_row<0x124>(acc.z); acc.w += dpp_row<0x124>(acc.w);
+            dc.x += dpp_row<0x124>(dc.x); dc.y += dpp_row<0x124>(dc.y);
+        }
+        if constexpr (W <= 16) {
+            acc.x = rows_sum(acc.x); acc.y = rows_sum(acc.y); acc.z = rows_sum(acc.z); acc.w = rows_sum(acc.w);
+            dc.x = rows_sum(dc.x); dc.y = rows_sum(dc.y);
+        } else if constexpr (W == 32) {
+            const auto sw = [](float v) {
+                const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+            };
+            acc.x = sw(acc.x); acc.y = sw(acc.y); acc.z = sw(acc.z); acc.w = sw(acc.w); dc.x = sw(dc.x); dc.y = sw(dc.y);
+        }
     }
-    if (lane < W) {                                    // W <= 64: lane == column
+    if (lane < W) {                                    // W <= 64: lane == column of the slice
         l_red[wave][lane] = acc;
         if (lane == 0) l_dc[wave] = dc;
     }

@@ -4,7 +4,7 @@
 // where a step spends its cycles.  Read SHARES, not totals: the stamps' fences forbid overlaps the product build has.
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DIRB_STAMPS -o tools/step_stamps tools/step_stamps.hip
-//   tools/step_stamps fused|cols  B  P  S  [W PS]
+//   tools/step_stamps fused|cols  B  P  S  [W PS U]
 #define IRB_STAMPS 1
 #include "../irbaboon_amd/csrc/fdl_kernels.hpp"
 
@@ -25,7 +25,7 @@ static const char *kCols[] = {"start", "all loads issued", "small loads in LDS (
                               "inverse split + FFT", "overlap-add landed"};
 
 template <int N>
-static void launch(const std::string &mode, irb::StepArgs a, unsigned *tickets, int S, int W, int PS, int *grid_out)
+static void launch(const std::string &mode, irb::StepArgs a, unsigned *tickets, int S, int W, int PS, int *grid_out, int U = 8)
 {
     if (mode == "fused") {
         *grid_out = S;
@@ -47,7 +47,7 @@ int main(int argc, char **argv)
     if (argc < 5) { std::fprintf(stderr, "usage: %s fused|cols B P S [W PS]\n", argv[0]); return 2; }
     const std::string mode = argv[1];
     const int B = std::atoi(argv[2]), P = std::atoi(argv[3]), S = std::atoi(argv[4]);
-    const int W = argc > 5 ? std::atoi(argv[5]) : 4, PS = argc > 6 ? std::atoi(argv[6]) : 1;
+    const int W = argc > 5 ? std::atoi(argv[5]) : 4, PS = argc > 6 ? std::atoi(argv[6]) : 1, U = argc > 7 ? std::atoi(argv[7]) : 8;
     int N = 32;
     while (N < 2 * B - 1) N *= 2;
     if (N != 256 && N != 512 && N != 1024) { std::fprintf(stderr, "B must give N in {256,512,1024}\n"); return 2; }
@@ -101,18 +101,34 @@ int main(int argc, char **argv)
     std::vector<double> sum(16, 0.0), sumlast(16, 0.0);
     std::vector<unsigned long long> st((size_t) maxgrid * 16);
     int nlast = 0, nall = 0;
+    std::vector<double> mx(16, 0.0);                    // per phase: the slowest workgroup, averaged over launches
+    double span_ticket = 0, span_total = 0, span_first = 0;   // 100 MHz clock: first start -> last ticket / -> end; first start -> last start
+    int nspan = 0;
     for (int it = 0; it < reps; it++) {
         a.head = it % R;
         CK(hipMemset(dst, 0, (size_t) maxgrid * 16 * sizeof(unsigned long long)));
         switch (N) {
-        case 256: launch<256>(mode, a, dtick, S, W, PS, &grid); break;
-        case 512: launch<512>(mode, a, dtick, S, W, PS, &grid); break;
-        default: launch<1024>(mode, a, dtick, S, W, PS, &grid); break;
+        case 256: launch<256>(mode, a, dtick, S, W, PS, &grid, U); break;
+        case 512: launch<512>(mode, a, dtick, S, W, PS, &grid, U); break;
+        default: launch<1024>(mode, a, dtick, S, W, PS, &grid, U); break;
         }
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
         if (it < 20) continue;                                   // warm-up
         CK(hipMemcpy(st.data(), dst, (size_t) grid * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        {
+            std::vector<double> m(16, 0.0);
+            unsigned long long r0min = ~0ull, r0max = 0, r7max = 0, r10max = 0;
+            for (int g = 0; g < grid; g++) {
+                const unsigned long long *t = &st[(size_t) g * 16];
+                for (int i = 1; i <= 7; i++) if (t[i] && t[i - 1]) m[i] = std::max(m[i], (double) (t[i] - t[i - 1]));
+                if (t[11]) { r0min = std::min(r0min, t[11]); r0max = std::max(r0max, t[11]); }
+                r7max = std::max(r7max, t[12]);
+                r10max = std::max(r10max, t[13]);
+            }
+            for (int i = 1; i <= 7; i++) mx[i] += m[i];
+            if (r10max && r0min != ~0ull) { span_ticket += (double) (r7max - r0min); span_total += (double) (r10max - r0min); span_first += (double) (r0max - r0min); nspan++; }
+        }
         for (int g = 0; g < grid; g++) {
             const unsigned long long *t = &st[(size_t) g * 16];
             const bool last = t[10] != 0;
@@ -126,16 +142,22 @@ int main(int argc, char **argv)
             if (last) nlast++;
         }
     }
-    std::printf("%s B=%d N=%d P=%d S=%d W=%d PS=%d grid=%d  (cycles of s_memtime = shader clock; ~40 per stamp not subtracted)\n",
-                mode.c_str(), B, N, P, S, W, PS, grid);
+    std::printf("%s B=%d N=%d P=%d S=%d W=%d PS=%d U=%d grid=%d  (cycles of s_memtime = shader clock; ~40 per stamp not subtracted)\n",
+                mode.c_str(), B, N, P, S, W, PS, U, grid);
     const char **names = mode == "fused" ? kFused : kCols;
     double tot = 0;
     for (int i = 1; i <= 10; i++) {
         const bool tail = mode != "fused" && i >= 8;
         const double v = tail ? (nlast ? sumlast[i] / nlast : 0.0) : (mode == "fused" ? sum[i] / std::max(nall, 1) : sum[i] / std::max(nall, 1));
         tot += v;
-        std::printf("  %2d %-40s %8.0f cyc%s\n", i, names[i], v, tail ? "  (last arriver only)" : "");
+        if (i <= 7 && mode != "fused")
+            std::printf("  %2d %-40s %8.0f cyc   slowest workgroup %8.0f\n", i, names[i], v, mx[i] / std::max(reps - 20, 1));
+        else
+            std::printf("  %2d %-40s %8.0f cyc%s\n", i, names[i], v, tail ? "  (last arriver only)" : "");
     }
+    if (nspan)
+        std::printf("  100 MHz clock: first workgroup start -> last start %.2f us, -> last ticket %.2f us, -> end of last arriver %.2f us\n",
+                    span_first / nspan / 100.0, span_ticket / nspan / 100.0, span_total / nspan / 100.0);
     std::printf("  sum %.0f cycles = %.2f us at 2.4 GHz\n", tot, tot / 2400.0);
     return 0;
 }
