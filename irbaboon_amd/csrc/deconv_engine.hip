@@ -95,6 +95,10 @@ int launch_tile(irb_lfft *p, const irb::LfftArgs &a, const float2 *src, float2 *
         auto k = irb::k_lfft_tile<MX, 8, INV, COLS>;
         if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
         else k<<<dim3(nwg), dim3(irb::kWave * 8), lds, p->stream>>>(a, src, dst);
+    } else if (R == 4) {
+        auto k = irb::k_lfft_tile<MX, 4, INV, COLS>;
+        if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
+        else k<<<dim3(nwg), dim3(irb::kWave * 4), lds, p->stream>>>(a, src, dst);
     } else {
         return irb_set_error_(IRB_ERR_ARG, "unsupported tile height");
     }
@@ -215,8 +219,10 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
     else { p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1; }
     p->logE = std::min(10, ilog2(p->N));
     if (p->M2 > 1) {
-        p->tile_rows = 8;                            // 16 leaves too few workgroups at 2^20 (tools/perf_probe.py lfft)
-        if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 8, 16
+        // rows / columns per workgroup: 8 gives 64-byte global pieces; a single 2^20 transform then has only 64-128
+        // workgroups for 256 CUs, so small batches take 4 (32-byte pieces, twice the workgroups: latency-bound anyway)
+        p->tile_rows = (long) max_batch * std::min(p->M1, p->M2) / 8 >= 256 ? 8 : 4;
+        if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 4, 8, 16
         if (p->tile_rows == 16 && std::max(p->M1, p->M2) > 1024) p->tile_rows = 8;
     }
     const int E = 1 << p->logE;
@@ -347,75 +353,114 @@ int irb_fft_inv_transform(int device, const float *in, int fft_size, float *out)
 }
 
 // ---- host-resident IR preparation ----------------------------------------------------------------------
+//
+// Fractional-octave smoothing (convolution::averagingFilter, fp/convolution.cpp:406-546) in three steps over the
+// complex bins c = 0..N/2 of an N-point real transform:
+//   1. every bin's window [c / r, c * r], r = 2^(fraction/2), rounded to whole bins (octave_windows);
+//   2. the mean over the window of log|X| (or of |X|), the window running past Nyquist where the spectrum is 0;
+//   3. the spectrum rebuilt from the new amplitude and the old phase (rebuild_bin).
+// Results must equal the reference's float for float, and step 2 is where that bites: the reference keeps ONE
+// float accumulator that slides along the spectrum (entering bins added, leaving bins subtracted, in that order),
+// so its rounding depends on the whole history.  sliding_mean reproduces exactly that accumulation order; it is
+// the reason this stays a sequential host loop (a parallel prefix sum in double differs from the float history
+// by up to 1e-3 at 2^20 points: tests/test_host_code.py::test_sliding_float_sum_drift).
 
-static void round_to_zero(float *x, float threshold)               // fp/tools.cpp:199-209
+}  // extern "C" (the helpers below are C++)
+
+namespace smoothing {
+
+constexpr float kAmplFloor = 1e-16f;                                // tools::roundTo1TenQuadrillionth, fp/tools.cpp:213-218
+constexpr float kZeroBelow = 1e-11f;                                // tools::roundToZero threshold, fp/convolution.cpp:534-536
+
+inline float floor_magnitude(float v)                               // |v| < 1e-16 -> +-1e-16, sign kept (+0 counts as positive)
 {
-    if (threshold < 0.0f) return;
-    if (!std::signbit(*x) && *x < threshold) *x = 0.0f;
-    if (std::signbit(*x) && *x > -(threshold)) *x = 0.0f;
+    // the reference compares the float with the DOUBLE constant 1e-16 and stores the float nearest to it
+    if (std::signbit(v)) return (double) v > -1e-16 ? -kAmplFloor : v;
+    return (double) v < 1e-16 ? kAmplFloor : v;
 }
 
-static void round_to_1e16(float *x)                                 // fp/tools.cpp:213-218
+inline float flush_small(float v)                                   // |v| < 1e-11 -> +0
 {
-    if (!std::signbit(*x) && *x < 1e-16) *x = 1e-16;
-    if (std::signbit(*x) && *x > -1e-16) *x = -1e-16;
+    if (std::signbit(v)) return v > -kZeroBelow ? 0.0f : v;
+    return v < kZeroBelow ? 0.0f : v;
 }
 
-// convolution::averagingFilter (fp/convolution.cpp:406-546), one channel, in place.  Sequential float
-// running sum of log amplitudes over a fractional-octave window: order sensitive, so it stays a host loop.
+struct Windows {
+    std::vector<int> first, last;                                   // per bin: the window's bounds, in bins (last may exceed N/2)
+};
+
+Windows octave_windows(int nbins, double hz_per_bin, double octave_fraction)      // fp/convolution.cpp:451-458
+{
+    Windows w;
+    w.first.resize((size_t) nbins);
+    w.last.resize((size_t) nbins);
+    const double ratio = std::pow(2.0, octave_fraction / 2.0);      // half of the fraction to either side
+    for (int c = 0; c < nbins; c++) {
+        const double centre_hz = c * hz_per_bin;
+        w.first[(size_t) c] = (int) std::round((centre_hz / ratio) / hz_per_bin);
+        w.last[(size_t) c] = (int) std::round((centre_hz * ratio) / hz_per_bin);
+    }
+    return w;
+}
+
+// mean[c] = (sum of value(j), j in window c) / window length, with the reference's accumulation order (:482-505,519):
+// one float accumulator; for each bin first the values that left the window are subtracted (ascending), then the
+// values that entered are added (ascending).  value(j) = v[j] for j < have, `pad` for have <= j < limit (bins between
+// Nyquist and the end of the reference's 2N-float buffer hold amplitude 0), and bins >= limit are not added at all
+// although they count in the window length (:497).
+void sliding_mean(const float *v, int have, int limit, float pad, const Windows &w, int nbins, float *mean)
+{
+    float acc = 0.0f;
+    int left = 0, right = -1;                                       // the window the accumulator currently covers: [left, right]
+    for (int c = 0; c < nbins; c++) {
+        const int first = w.first[(size_t) c], last = w.last[(size_t) c];
+        for (; left < first; left++) acc -= left < have ? v[left] : pad;
+        for (int j = right + 1; j <= last; j++)
+            if (j < limit) acc += j < have ? v[j] : pad;
+        right = last;
+        mean[c] = (float) (acc / ((double) (last - first) + 1.0));
+    }
+}
+
+// the linear-average variant restarts its sum for every bin (:507-516)
+void restarted_mean(const float *v, int limit, const Windows &w, int nbins, float *mean)
+{
+    for (int c = 0; c < nbins; c++) {
+        const int first = w.first[(size_t) c], last = w.last[(size_t) c];
+        float acc = 0.0f;
+        for (int j = first; j <= last && j < limit; j++) acc += v[j];
+        mean[c] = (float) (acc / ((double) (last - first) + 1.0));
+    }
+}
+
+}  // namespace smoothing
+
+extern "C" {
+
+// convolution::averagingFilter (fp/convolution.cpp:406-546), one channel, in place, HOST code.
+// buffer: fft_size = 2N floats, interleaved (re, im) for bins 0..N/2.
 void irb_averaging_filter(float *buffer, int fft_size, double octave_fraction, double sample_rate, int log_avg,
                           int include_phase, int include_amplitude)
 {
     if (!buffer || !is_pow2(fft_size)) return;                      // :412-415 (DBG + return)
-    std::vector<float> oldAmpl((size_t) fft_size / 2, 0.0f), newAmpl((size_t) fft_size, 0.0f);
-    const int N = fft_size / 2;
-    const double fractPerSide = octave_fraction / 2.0;
-    const double freqPerBin = (sample_rate / 2) / (double) (N / 2);
-    for (int bin = 0; bin <= N; bin += 2)
-        oldAmpl[bin / 2] = (float) std::sqrt(std::pow((double) buffer[bin], 2.0) + std::pow((double) buffer[bin + 1], 2.0));
-    // Same values, same order as the reference loop -- only loop-invariant work is hoisted: pow(2, fract) is a
-    // constant, and the log of a bin's amplitude is needed when it enters and when it leaves the window.
-    const double up = std::pow(2.0, fractPerSide);
-    std::vector<float> logAmpl;
+    const int n = fft_size / 2, nbins = n / 2 + 1;                  // transform length, bins 0..N/2
+    const smoothing::Windows win = smoothing::octave_windows(nbins, (sample_rate / 2) / (double) (n / 2), octave_fraction);
+    float2 *bins = reinterpret_cast<float2 *>(buffer);
+    std::vector<float> ampl((size_t) n, 0.0f), mean((size_t) nbins);     // amplitudes of bins 0..N-1: zero above Nyquist
+    for (int c = 0; c < nbins; c++)                                 // tools::binAmpl: double arithmetic, float result
+        ampl[(size_t) c] = (float) std::sqrt(std::pow((double) bins[c].x, 2.0) + std::pow((double) bins[c].y, 2.0));
     if (log_avg) {
-        logAmpl.resize(oldAmpl.size());
-        for (size_t i = 0; i < oldAmpl.size(); i++) {
-            float v = oldAmpl[i];
-            round_to_1e16(&v);
-            logAmpl[i] = std::log(v);
-        }
+        for (int c = 0; c < nbins; c++) ampl[(size_t) c] = std::log(smoothing::floor_magnitude(ampl[(size_t) c]));
+        smoothing::sliding_mean(ampl.data(), nbins, n, std::log(smoothing::kAmplFloor), win, nbins, mean.data());
+        for (int c = 0; c < nbins; c++) mean[(size_t) c] = std::exp(mean[(size_t) c]);
+    } else {
+        smoothing::restarted_mean(ampl.data(), n, win, nbins, mean.data());
     }
-    float runningSum = 0.0f;
-    int prevLowerBin = 0, prevUpperBin = -2;
-    for (int bin = 0; bin <= N; bin += 2) {
-        const double binFreq = (bin / 2) * freqPerBin;
-        const int lowerBin = 2 * (int) std::round((binFreq / up) / freqPerBin);
-        const int upperBin = 2 * (int) std::round((binFreq * up) / freqPerBin);
-        const double binRangeLength = (double) (upperBin - lowerBin) / 2.0 + 1.0;
-        if (log_avg) {
-            for (int sb = prevLowerBin; sb < lowerBin; sb += 2) runningSum -= logAmpl[sb / 2];
-            for (int ab = prevUpperBin + 2; ab <= upperBin; ab += 2)
-                if (ab < fft_size) runningSum += logAmpl[ab / 2];
-        } else {
-            runningSum = 0.0f;
-            for (int i = lowerBin; i <= upperBin && i / 2 < fft_size / 2; i += 2) runningSum += oldAmpl[i / 2];
-        }
-        float na = (float) (runningSum / binRangeLength);
-        if (log_avg) na = std::exp(na);
-        round_to_1e16(&na);
-        newAmpl[bin] = na;
-        prevLowerBin = lowerBin;
-        prevUpperBin = upperBin;
-    }
-    for (int bin = 0; bin <= N; bin += 2) {
-        float ampl = newAmpl[bin];
-        round_to_zero(buffer + bin, 1e-11f);
-        round_to_zero(buffer + bin + 1, 1e-11f);
-        float phase = std::atan2(buffer[bin + 1], buffer[bin]);
-        if (!include_amplitude) ampl = 1.0f;
-        if (!include_phase) phase = 0.0f;
-        buffer[bin] = ampl * std::cos(phase);
-        buffer[bin + 1] = ampl * std::sin(phase);
+    for (int c = 0; c < nbins; c++) {                               // :531-543
+        const float magnitude = include_amplitude ? smoothing::floor_magnitude(mean[(size_t) c]) : 1.0f;
+        const float re = smoothing::flush_small(bins[c].x), im = smoothing::flush_small(bins[c].y);
+        const float phase = include_phase ? std::atan2(im, re) : 0.0f;
+        bins[c] = make_float2(magnitude * std::cos(phase), magnitude * std::sin(phase));
     }
 }
 
@@ -436,41 +481,22 @@ void irb_shifteroo(float *buf, int n)                               // fp/ir.cpp
 static int smooth_on_device(irb_lfft *p, float *d_spec, int N, double octave_fraction, double sample_rate,
                             int passes, int include_phase, int include_amplitude)
 {
-    const int nb = N / 2 + 1;                                       // bins 0..N/2; fft_size = 2N, reference "N" = N
-    const int fft_size = 2 * N;
-    const double fractPerSide = octave_fraction / 2.0;
-    const double freqPerBin = (sample_rate / 2) / (double) (N / 2);
-    const double up = std::pow(2.0, fractPerSide);
-    std::vector<int> lo((size_t) nb), hi((size_t) nb);              // window bounds in complex-bin units (:451-458)
-    for (int b = 0; b < nb; b++) {
-        const double binFreq = b * freqPerBin;
-        lo[b] = (int) std::round((binFreq / up) / freqPerBin);
-        hi[b] = (int) std::round((binFreq * up) / freqPerBin);
-    }
-    float tiny = 1e-16f;
-    const float logMin = std::log(tiny);                            // bins above Nyquist count as amplitude 0 -> 1e-16 (:497)
-    std::vector<float> logA((size_t) nb), avg((size_t) nb);
-    float *d_logA = reinterpret_cast<float *>(p->d_w0), *d_avg = reinterpret_cast<float *>(p->d_w1);   // work buffers are idle here
+    const int nbins = N / 2 + 1;
+    const smoothing::Windows win = smoothing::octave_windows(nbins, (sample_rate / 2) / (double) (N / 2), octave_fraction);
+    const float pad = std::log(smoothing::kAmplFloor);              // bins above Nyquist count as amplitude 0 -> 1e-16
+    std::vector<float> log_ampl((size_t) nbins), mean((size_t) nbins);
+    float *d_log = reinterpret_cast<float *>(p->d_w0), *d_mean = reinterpret_cast<float *>(p->d_w1);   // work buffers are idle here
     for (int pass = 0; pass < passes; pass++) {
-        irb::k_smooth_log_ampl<<<dim3((nb + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<const float2 *>(d_spec), d_logA, nb);
+        irb::k_smooth_log_ampl<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<const float2 *>(d_spec), d_log, nbins);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(logA.data(), d_logA, sizeof(float) * nb, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(log_ampl.data(), d_log, sizeof(float) * nbins, hipMemcpyDeviceToHost, p->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
         if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (log amplitudes)", hipGetErrorString(e));
-        float runningSum = 0.0f;                                    // :482-505, float, sequential
-        int prevLo = 0, prevHi = -1;
-        for (int b = 0; b < nb; b++) {
-            for (int sb = prevLo; sb < lo[b]; sb++) runningSum -= logA[sb];
-            for (int ab = prevHi + 1; ab <= hi[b]; ab++)
-                if (2 * ab < fft_size) runningSum += (ab < nb ? logA[ab] : logMin);
-            avg[b] = (float) (runningSum / ((double) (hi[b] - lo[b]) + 1.0));       // :519 (log domain; exp on device)
-            prevLo = lo[b];
-            prevHi = hi[b];
-        }
-        e = hipMemcpyAsync(d_avg, avg.data(), sizeof(float) * nb, hipMemcpyHostToDevice, p->stream);
+        smoothing::sliding_mean(log_ampl.data(), nbins, N, pad, win, nbins, mean.data());     // the order-sensitive float history
+        e = hipMemcpyAsync(d_mean, mean.data(), sizeof(float) * nbins, hipMemcpyHostToDevice, p->stream);
         if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (averages)", hipGetErrorString(e));
-        irb::k_smooth_apply<<<dim3((nb + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(d_spec), d_avg, nb, 1,
-                                                                                   include_phase, include_amplitude);
+        irb::k_smooth_apply<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(d_spec), d_mean, nbins, 1,
+                                                                                      include_phase, include_amplitude);
         if ((e = hipGetLastError()) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "k_smooth_apply", hipGetErrorString(e));
         if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing", hipGetErrorString(e));
     }
@@ -525,75 +551,92 @@ int irb_invert_filter(int device, const float *ir, int len, int sample_rate, flo
 }
 
 // ---- fp::ExpSineSweep (host) ---------------------------------------------------------------------------
+// Farina's exponential sine sweep x[i] = sin(K (e^(i/L) - 1)) over T = rate * duration samples between the angular
+// frequencies w_lo and w_hi (radians per sample): L = T / ln(w_hi / w_lo) is the e-folding time of the instantaneous
+// frequency and K = w_lo L its phase scale.  The frequency doubles every T / log2(w_hi / w_lo) samples, which is all
+// the index <-> frequency maps use.  Arithmetic follows fp/ExpSineSweep.cpp operation for operation (doubles), so
+// that generated sweeps are the reference's sample for sample.
 namespace {
-struct SweepPar { double SR, w1, w2, T, K, L; };
-SweepPar sweep_par(double durationSecs, double sampleRate, double lowFreq, double highFreq)   // fp/ExpSineSweep.cpp:212-220
-{
-    SweepPar p;
-    p.SR = sampleRate;
-    p.T = p.SR * durationSecs;
-    p.w1 = lowFreq / p.SR * 2 * M_PI;
-    p.w2 = highFreq / p.SR * 2 * M_PI;
-    p.K = p.T * p.w1 / std::log(p.w2 / p.w1);
-    p.L = p.T / std::log(p.w2 / p.w1);
-    return p;
-}
-bool sweep_args_ok(double d, double sr, double lo, double hi) { return d > 0 && sr > 0 && lo > 0 && hi > lo; }
+
+struct FarinaSweep {
+    double rate, samples, w_lo, w_hi;
+
+    static bool valid(double duration, double rate, double f_lo, double f_hi) { return duration > 0 && rate > 0 && f_lo > 0 && f_hi > f_lo; }
+
+    FarinaSweep(double duration, double rate_, double f_lo, double f_hi)                          // fp/ExpSineSweep.cpp:212-220
+        : rate(rate_), samples(rate_ * duration), w_lo(f_lo / rate_ * 2 * M_PI), w_hi(f_hi / rate_ * 2 * M_PI) {}
+
+    int length() const { return (int) samples; }
+    double efold() const { return samples / std::log(w_hi / w_lo); }                              // L
+    double phase_scale() const { return samples * w_lo / std::log(w_hi / w_lo); }                 // K
+    double octaves() const { return std::log(w_hi / w_lo) / std::log(2); }
+    double start_hz() const { return w_lo * rate / (2 * M_PI); }
+
+    void render(double gain, double *out) const                                                   // :26-41
+    {
+        const double K = phase_scale(), L = efold();
+        for (int i = 0, n = length(); i < n; i++) out[i] = gain * std::sin(K * (std::exp((double) i / L) - 1.0));
+    }
+    // time-reversed sweep with a -6 dB/octave envelope: the matched inverse filter (:59-79)
+    void render_inverse(double gain, double *out) const
+    {
+        const int n = length();
+        render(gain, out);
+        std::reverse(out, out + n);
+        const double per_sample = std::pow(10.0, (-6.0 * std::log2(w_hi / w_lo)) / 20.0 / samples);
+        double envelope = per_sample;
+        for (int i = 0; i < n; i++) { out[i] *= envelope; envelope *= per_sample; }
+    }
+    int index_of(double hz) const                                                                 // :243-258; -1: not in this sweep
+    {
+        const int i = (int) std::round(std::log(hz / start_hz()) / std::log(2) / octaves() * samples);
+        return (i < 0 || i >= samples) ? -1 : i;
+    }
+    double hz_at(int index) const { return start_hz() * std::pow(2.0, (double) index / samples * octaves()); }   // :225-240
+};
+
 }  // namespace
 
 int irb_sweep_generate(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
-                       double *out, int out_len)                                                // :26-41
+                       double *out, int out_len)
 {
-    if (!out || !sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq)) return irb_set_error_(IRB_ERR_ARG, "bad sweep parameters");
-    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
-    const int n = (int) p.T;
-    if (out_len < n) return irb_set_error_(IRB_ERR_ARG, "out too small for the sweep");
-    const double gain = std::pow(10.0, dB_gain / 20.0);                                          // tools::dBToLin
-    for (int i = 0; i < n; i++) out[i] = gain * std::sin(p.K * (std::exp((double) i / p.L) - 1.0));
-    return n;
+    if (!out || !FarinaSweep::valid(duration_secs, sample_rate, low_freq, high_freq)) return irb_set_error_(IRB_ERR_ARG, "bad sweep parameters");
+    const FarinaSweep sw(duration_secs, sample_rate, low_freq, high_freq);
+    if (out_len < sw.length()) return irb_set_error_(IRB_ERR_ARG, "out too small for the sweep");
+    sw.render(std::pow(10.0, dB_gain / 20.0), out);                                               // tools::dBToLin
+    return sw.length();
 }
 
 int irb_sweep_generate_inv(double duration_secs, double sample_rate, double low_freq, double high_freq, double dB_gain,
-                           double *out, int out_len)                                            // :59-79
+                           double *out, int out_len)
 {
-    const int n = irb_sweep_generate(duration_secs, sample_rate, low_freq, high_freq, dB_gain, out, out_len);
-    if (n < 0) return n;
-    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
-    std::reverse(out, out + n);
-    const double k = std::pow(10.0, (-6.0 * std::log2(p.w2 / p.w1)) / 20.0 / p.T);             // -6 dB/oct
-    double kIterator = k;
-    for (int i = 0; i < n; i++) { out[i] *= kIterator; kIterator *= k; }
-    return n;
+    if (!out || !FarinaSweep::valid(duration_secs, sample_rate, low_freq, high_freq)) return irb_set_error_(IRB_ERR_ARG, "bad sweep parameters");
+    const FarinaSweep sw(duration_secs, sample_rate, low_freq, high_freq);
+    if (out_len < sw.length()) return irb_set_error_(IRB_ERR_ARG, "out too small for the sweep");
+    sw.render_inverse(std::pow(10.0, dB_gain / 20.0), out);
+    return sw.length();
 }
 
-int irb_sweep_sample_index_at_freq(double freq, double duration_secs, double sample_rate, double low_freq, double high_freq)   // :243-258
+int irb_sweep_sample_index_at_freq(double freq, double duration_secs, double sample_rate, double low_freq, double high_freq)
 {
-    if (!sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq) || !(freq > 0)) return -1;
-    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
-    const double lf = (p.w1 * p.SR / (2 * M_PI));
-    const double oct = std::log(freq / lf) / std::log(2);
-    const double totalOct = std::log(p.w2 / p.w1) / std::log(2);
-    const int t_rounded = (int) std::round(oct / totalOct * p.T);
-    if (t_rounded < 0 || t_rounded >= p.T) return -1;                                            // "out of bounds for this sweep"
-    return t_rounded;
+    if (!FarinaSweep::valid(duration_secs, sample_rate, low_freq, high_freq) || !(freq > 0)) return -1;
+    return FarinaSweep(duration_secs, sample_rate, low_freq, high_freq).index_of(freq);
 }
 
-double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sample_rate, double low_freq, double high_freq)   // :225-240
+double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sample_rate, double low_freq, double high_freq)
 {
-    if (!sweep_args_ok(duration_secs, sample_rate, low_freq, high_freq)) return -1;
-    const SweepPar p = sweep_par(duration_secs, sample_rate, low_freq, high_freq);
-    if (index < 0 || index >= (int) p.T) return -1;
-    const double lf = p.w1 * p.SR / (2 * M_PI);
-    const double totalOct = std::log(p.w2 / p.w1) / std::log(2);
-    return lf * std::pow(2.0, (double) index / p.T * totalOct);
+    if (!FarinaSweep::valid(duration_secs, sample_rate, low_freq, high_freq)) return -1;
+    const FarinaSweep sw(duration_secs, sample_rate, low_freq, high_freq);
+    return (index < 0 || index >= sw.length()) ? -1 : sw.hz_at(index);
 }
 
-int irb_sweep_lin_fadeout(double *sweep, int n, int index)                                      // :147-164
+// ExpSineSweep::linFadeout (:147-164): linear ramp to zero from sample `index` to the end
+int irb_sweep_lin_fadeout(double *sweep, int n, int index)
 {
     if (!sweep || n < 0) return irb_set_error_(IRB_ERR_ARG, "bad argument");
     if (n == 0 || index < 0 || index >= n) return IRB_OK;                                         // nothing to fade
-    const int fadeoutSampleLength = n - index;
-    for (int i = index; i < n; i++) sweep[i] = sweep[i] * (fadeoutSampleLength - (i - index)) / fadeoutSampleLength;
+    const int span = n - index;
+    for (int i = index; i < n; i++) sweep[i] = sweep[i] * (span - (i - index)) / span;
     return IRB_OK;
 }
 

@@ -67,11 +67,12 @@ struct irb_fdl {
 
     float2 *d_H = nullptr, *d_X = nullptr, *d_tw = nullptr, *d_part = nullptr;
     float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
-    int *d_set_of_stream = nullptr, *d_np_of_set = nullptr;
+    int2 *d_stream_info = nullptr;          // [S] {IR set, partitions in use}: what the kernels read
     unsigned *d_tickets = nullptr;           // [S] arrival counters of k_step_split
     float *h_io = nullptr;                   // pinned: [S][Tmax*B]
     float *h_ir = nullptr;                   // pinned: [C][P*B]
-    int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // pinned mirrors
+    int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // host: IR set of every stream, partitions in use of every set
+    int2 *h_info = nullptr;                  // pinned staging of d_stream_info
 };
 
 namespace {
@@ -177,7 +178,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     irb::StepArgs a;
     a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
-    a.set_of_stream = h->d_set_of_stream; a.np_of_set = h->d_np_of_set;
+    a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
     a.B = h->B; a.P = h->Ppad; a.R = h->R; a.head = (int) (h->t % h->R); a.splits = h->splits;
@@ -261,8 +262,9 @@ int upload_maps(irb_fdl *h)
 {
     h->pair = (h->C == 2) && !(h->flags & IRB_FDL_NO_PAIRING);
     for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
-    HIP_TRY(hipMemcpyAsync(h->d_set_of_stream, h->h_set_of_stream, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_np_of_set, h->h_np_of_set, sizeof(int) * h->S, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the pinned staging may still feed an earlier upload
+    for (int s = 0; s < h->S; s++) h->h_info[s] = make_int2(h->h_set_of_stream[s], h->h_np_of_set[h->h_set_of_stream[s]]);
+    HIP_TRY(hipMemcpyAsync(h->d_stream_info, h->h_info, sizeof(int2) * h->S, hipMemcpyHostToDevice, h->stream));
     return IRB_OK;
 }
 
@@ -283,11 +285,12 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
-    (void) hipFree(h->d_set_of_stream); (void) hipFree(h->d_np_of_set); (void) hipFree(h->d_tickets);
+    (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
     if (h->h_np_of_set) (void) hipHostFree(h->h_np_of_set);
+    if (h->h_info) (void) hipHostFree(h->h_info);
     for (auto &e : h->ev) if (e) (void) hipEventDestroy(e);
     if (h->own_stream && h->stream) (void) hipStreamDestroy(h->stream);
     delete h;
@@ -350,14 +353,14 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (!guard(dev_alloc(h, &h->d_in, (size_t) h->S * h->Tmax * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_out, (size_t) h->S * h->Tmax * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_irtime, (size_t) h->C * h->P * h->B))) break;
-        if (!guard(dev_alloc(h, &h->d_set_of_stream, (size_t) h->S))) break;
-        if (!guard(dev_alloc(h, &h->d_np_of_set, (size_t) h->S))) break;
+        if (!guard(dev_alloc(h, &h->d_stream_info, (size_t) h->S))) break;
         if (!guard(dev_alloc(h, &h->d_tickets, (size_t) h->S))) break;
         hipError_t e;
         if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) h->S * h->Tmax * h->B)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_set_of_stream), sizeof(int) * h->S)) != hipSuccess ||
-            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess) {
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info), sizeof(int2) * h->S)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
             break;
         }

@@ -42,8 +42,8 @@ struct StepArgs {
     float2       *X;            // [S][R][M]
     float        *ovl;          // [S][B]
     const float2 *tw;           // [N]
-    const int    *set_of_stream;// [S]
-    const int    *np_of_set;    // [n_sets]: partitions in use (<= P)
+    const int2   *stream_info;  // [S]: x = IR set the stream multiplies with, y = partitions in use (<= P) of that set;
+                                // ONE 8-byte record so a workgroup learns both with a single (scalar) load before its first row
     const float  *in;           // block j of stream s at in + s*in_stride + j*B
     float        *out;
     float2       *part;         // [S][splits][M] partial sums (split path)
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(kThreads) void k_step_fused(StepArgs a)
     __shared__ Lds<N> lds;
     const int s = blockIdx.x;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     float2 *Xs = a.X + (size_t) s * a.R * M;
     const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
     __shared__ LdsPair<N> lds;
     const int s0 = 2 * blockIdx.x;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int set = a.set_of_stream[s0];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s0];
+    const int set = si.x, np = si.y;
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     float2 *Xs[2] = {a.X + (size_t) s0 * a.R * M, a.X + (size_t) (s0 + 1) * a.R * M};
     const float4 *X4[2] = {reinterpret_cast<const float4 *>(Xs[0]), reinterpret_cast<const float4 *>(Xs[1])};
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(kThreads) void k_cmac_partial(StepArgs a)
     __shared__ float2 part[G::STRIPES * M];
     __shared__ float2 Y[M];
     const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     const int kb = (int) ((long) np * j / a.splits), ke = (int) ((long) np * (j + 1) / a.splits);
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *_
     __shared__ unsigned l_ticket;
     const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     // Partition 0 pairs with the block that split 0 transforms in THIS launch, so it always belongs to split 0
     // (through LDS); only the older partitions [1, np) are divided over the splits.  np comes from the IR in use,
     // splits from the engine's capacity: np < splits just leaves some splits with an empty range.
@@ -735,8 +735,8 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // neighbouring column slices share an XCD's L2
     const int cs = wg % CS, ps = (wg / CS) % PS, s = wg / (CS * PS);
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     // partition 0 pairs with the block transformed in this launch and belongs to range 0; the older partitions
     // [1, np) are divided in proportion to the loader waves: 3 in a workgroup of range 0, 4 in the others
     const int nold = np > 0 ? np - 1 : 0;
@@ -991,8 +991,8 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
     const int ntiles = (a.T + TT - 1) / TT;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     // the stripe index is the same for a whole wave (LW >= 64 for every supported N >= 256; smaller N are not
     // worth tuning): telling the compiler so keeps partition indices and ring slots in scalar registers
     const int col0 = threadIdx.x % G::LW;
@@ -1062,8 +1062,8 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
     const int ntiles = (a.T + TT - 1) / TT;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
-    const int set = a.set_of_stream[s];
-    const int np = a.np_of_set[set];
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
     const int col0 = threadIdx.x % LW;
     const int stripe = LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / LW) : (int) (threadIdx.x / LW);
     const int q = split * STRIPES + stripe;

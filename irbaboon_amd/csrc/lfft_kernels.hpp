@@ -124,10 +124,24 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     float2 *mine = tile + wave * LD;
     wave_fft<MX, INV>(mine, l_tw, lane);
     if (COLS) {
+        // inter-pass factor W_M^(n2*k1) = A[e / E] * B[e % E]: all table loads of this lane first (one memory
+        // latency instead of one per element), then the products
         const unsigned n2 = (unsigned) (i0 + wave);
-        for (int k1 = lane; k1 < MX; k1 += kWave) {
-            const float2 w = big_twiddle(a, 2u * n2 * (unsigned) k1);    // W_M^(n2*k1)
-            mine[k1] = INV ? cmulc(mine[k1], w) : cmul(mine[k1], w);
+        constexpr int KPL = MX >= kWave ? MX / kWave : 1;
+        float2 wa[KPL], wb[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
+            wa[i] = a.tabA[e >> a.logE];
+            wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
+        }
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const int k1 = lane + i * kWave;
+            if (MX >= kWave || k1 < MX) {
+                const float2 w = cmul(wa[i], wb[i]);
+                mine[k1] = INV ? cmulc(mine[k1], w) : cmul(mine[k1], w);
+            }
         }
     }
     __syncthreads();

@@ -117,6 +117,49 @@ def test_config5_full_size_one_million_samples():
     assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
 
 
+def test_config5_full_size_default_smoothing_and_inversion():
+    """BASELINE configs[4] at 2^20 samples with the chain's DEFAULTS: deconvolve with its three 1/13-octave
+    smoothing passes (fp/convolution.cpp:389-394) and ir::invertFilter (fp/ir.cpp:13-18), against the oracle.
+    Well-conditioned spectra (|D| bounded away from zero) so the whole band can be held to 1e-5; the sweep
+    capture with smoothing is compared where the division is conditioned (40 Hz..20 kHz)."""
+    sr, N = 48000, 1 << 20
+    den = decaying_ir(5, N)
+    den[0] += 4.0
+    h = decaying_ir(6, 4096)
+    num = np.fft.irfft(np.fft.rfft(den.astype(np.float64)) * np.fft.rfft(h.astype(np.float64), N), N).astype(np.float32)
+    for phase, ampl in ((True, True), (False, True)):
+        got = ib.deconvolve(num, den, sr, True, phase, ampl)
+        ref = oracle.deconvolve(num, den, sr, True, phase, ampl)
+        assert got.shape == ref.shape == (N,)
+        assert rel_rms(got, ref) < 1e-5
+    hh = decaying_ir(7, N)
+    hh[0] += 2.0
+    got, ref = ib.invertFilter(hh, sr), oracle.invert_filter(hh, sr)
+    assert got.shape == ref.shape == (N,) and rel_rms(got, ref) < 1e-5
+    sweep = exp_sine_sweep(3 * N // 4, sr, 20.0, sr / 2, fade_from=(11.0 / 12.0) * sr / 2, n_total=N)
+    cap = np.fft.irfft(np.fft.rfft(sweep.astype(np.float64)) * np.fft.rfft(h.astype(np.float64), N), N).astype(np.float32)
+    G = np.fft.rfft(ib.deconvolve(cap, sweep, sr, True).astype(np.float64))
+    R = np.fft.rfft(oracle.deconvolve(cap, sweep, sr, True).astype(np.float64))
+    band = slice(int(40 / sr * N), int(20000 / sr * N))
+    assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
+
+
+@pytest.mark.parametrize("tile", ["0", "4", "8", "16"])
+def test_large_fft_tile_heights(monkeypatch, tile):
+    """every tiling of the four-step passes (IRB_LFFT_TILE: rows / columns per workgroup; 0 = one wave per item)
+    gives the same transform: 2^14 .. 2^21 points, batch 1 and 3"""
+    monkeypatch.setenv("IRB_LFFT_TILE", tile)
+    ib.lib().irb_release_cached_plans()
+    for n in (1 << 14, 1 << 17, 1 << 20, 1 << 21):
+        x = white_noise(n + int(tile), n)
+        F = ib.fftTransform(x)
+        ref = np.fft.rfft(x.astype(np.float64))
+        got = _bins(F, n)
+        assert np.sqrt(np.mean(np.abs(got - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 2e-6
+        assert rel_rms(ib.fftInvTransform(F), x) < 1e-5
+    ib.lib().irb_release_cached_plans()
+
+
 # ---- SURVEY section 8(f) ranks 3 and 4 ----------------------------------------------------------------
 import os  # noqa: E402
 

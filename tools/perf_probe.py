@@ -67,6 +67,35 @@ def few(I=1, C=2, B=128, Lh=480000, n=2000, flags=0):
           f"{ms/n*1e3:.2f} us/step  {I*C*B/(ms/n)/1e3:.1f} Msamples/s  {alg/(ms/n)/1e6:.0f} GB/s algorithmic")
 
 
+def twoqueue(I=2048, B=256, Lh=96000, n=300, parts=2):
+    """the headline batch as `parts` engines of I/parts instances, each on its own HIP stream, stepped in turn with no
+    join between them: in steady state one part's launch gap / ramp-up / tail overlaps the other's streaming.  Shows how
+    much of the single-launch step time is per-launch fixed cost (the roofline line itself stays single-launch)."""
+    per = I // parts
+    engs = []
+    for p in range(parts):
+        e = FdlEngine(per, 1, B, Lh, max_blocks_per_call=1)
+        for i in range(per):
+            e.set_ir(i, decaying_ir(1 + p * per + i, Lh))
+        d_in, d_out, stride = e.device_io()
+        e.upload(d_in, np.stack([white_noise(5 + p * per + s, B) for s in range(per)]))
+        engs.append((e, d_in, d_out, stride))
+    def steps(k):
+        for _ in range(k):
+            for e, di, do, st in engs:
+                e.process_device(di, do, st, 1)
+    steps(20)
+    for e, *_ in engs:
+        e.synchronize()
+    t0 = time.perf_counter()
+    steps(n)
+    for e, *_ in engs:
+        e.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    alg = I * engs[0][0].info.algorithmic_bytes_per_block_step
+    print(f"twoqueue I={I} parts={parts} B={B} Lh={Lh}: {dt*1e6:.1f} us/step (wall)  {I*B/dt/1e6:.1f} Msamples/s  {alg/dt/1e9:.0f} GB/s algorithmic")
+
+
 def stereo(I=1024, B=256, Lh=96000, flags=0):
     """stereo instances with a mono IR (the plug-in's real-time layout), one block per call"""
     eng = FdlEngine(I, 2, B, Lh, max_blocks_per_call=1, flags=flags)
@@ -162,4 +191,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi, "few": few}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi, "few": few, "twoqueue": twoqueue}[mode](*args)

@@ -56,7 +56,7 @@ int main(int argc, char **argv)
 
     float2 *dH, *dX, *dtw, *dpart;
     float *dovl, *din, *dout;
-    int *dset, *dnp;
+    int2 *dinfo;
     unsigned *dtick;
     unsigned long long *dst;
     const int maxgrid = S * (M / 2) * std::max(PS, 1) + 16;
@@ -67,8 +67,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dovl, (size_t) S * B * sizeof(float)));
     CK(hipMalloc(&din, (size_t) S * B * sizeof(float)));
     CK(hipMalloc(&dout, (size_t) S * B * sizeof(float)));
-    CK(hipMalloc(&dset, S * sizeof(int)));
-    CK(hipMalloc(&dnp, S * sizeof(int)));
+    CK(hipMalloc(&dinfo, S * sizeof(int2)));
     CK(hipMalloc(&dtick, S * sizeof(unsigned)));
     CK(hipMalloc(&dst, (size_t) maxgrid * 16 * sizeof(unsigned long long)));
     {
@@ -82,17 +81,16 @@ int main(int argc, char **argv)
         CK(hipMemcpy(dtw, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice));
         std::vector<float> x((size_t) S * B, 0.25f);
         CK(hipMemcpy(din, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<int> set(S), np(S, P);
-        for (int s = 0; s < S; s++) set[s] = s;
-        CK(hipMemcpy(dset, set.data(), S * sizeof(int), hipMemcpyHostToDevice));
-        CK(hipMemcpy(dnp, np.data(), S * sizeof(int), hipMemcpyHostToDevice));
+        std::vector<int2> info(S);
+        for (int s = 0; s < S; s++) info[s] = make_int2(s, P);
+        CK(hipMemcpy(dinfo, info.data(), S * sizeof(int2), hipMemcpyHostToDevice));
         CK(hipMemset(dovl, 0, (size_t) S * B * sizeof(float)));
         CK(hipMemset(dtick, 0, S * sizeof(unsigned)));
     }
     irb::StepArgs a;
     std::memset(&a, 0, sizeof a);
     a.stamps = dst;
-    a.H = dH; a.X = dX; a.ovl = dovl; a.ovl_next = dovl; a.tw = dtw; a.set_of_stream = dset; a.np_of_set = dnp;
+    a.H = dH; a.X = dX; a.ovl = dovl; a.ovl_next = dovl; a.tw = dtw; a.stream_info = dinfo;
     a.in = din; a.out = dout; a.part = dpart; a.in_stride = B; a.out_stride = B;
     a.B = B; a.P = Ppad; a.R = R; a.splits = PS; a.T = 1; a.nq = 1;
 
