@@ -138,6 +138,71 @@ def pcie_inclusive(eng, np, x, reps=30):
             "note": "irb_fdl_process_packed, pinned host buffers, one block per instance per call, wall clock incl. H2D/D2H"}
 
 
+def traffic_child(instances, dev):
+    """`bench.py --traffic-child`: the timed launch and nothing else (same engine geometry and instance count, 12
+    one-block steps), so that a rocprofv3 --pmc pass over this process sees the headline kernel's HBM counters."""
+    import numpy as np
+    from irbaboon_amd import FdlEngine
+    from irbaboon_amd.synth import decaying_ir, white_noise
+    eng = FdlEngine(instances, 1, B, LH, max_blocks_per_call=NB, device=dev)
+    h = decaying_ir(18000, LH)
+    for i in range(instances):
+        eng.set_ir(i, h)                        # traffic does not depend on the IR values
+    d_in, d_out, stride = eng.device_io()
+    eng.upload(d_in, np.tile(white_noise(2000, NB * B), (instances, 1)))
+    for k in range(12):
+        off = (k % NB) * B * 4
+        eng.process_device(d_in + off, d_out + off, stride, 1)
+    eng.synchronize()
+    eng.close()
+
+
+def measure_traffic(instances, dev, kernel="k_step_fused"):
+    """HBM bytes per launch of the headline kernel, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, no tracing, the program directly after `--`),
+    corrected as MI355X_MICROARCH.md section HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE reports half
+    of a wide (16 B per lane) streaming read and is doubled; WRITE_SIZE is exact.  Returns (bytes, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this process is itself being profiled (no nested profiler)"
+    tmp = tempfile.mkdtemp(prefix="irb_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", "--instances", str(instances), "--device", str(dev)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-200:]}"
+            v = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
+                 if kernel in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not v:
+                return None, f"no {ctr} rows for {kernel}"
+            vals[ctr] = (statistics.mean(v), len(v))
+    except Exception as e:                      # a profiler problem must never take the bench line down
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_b = vals["FETCH_SIZE"][0] * 1024 * 2
+    write_b = vals["WRITE_SIZE"][0] * 1024
+    return fetch_b + write_b, (f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over {vals['FETCH_SIZE'][1]} + "
+                               f"{vals['WRITE_SIZE'][1]} dispatches; FETCH_SIZE x2 (gfx950 half-count), KiB -> bytes; "
+                               f"read {fetch_b:.0f} B + write {write_b:.0f} B per launch")
+
+
 def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     """The other BASELINE.json configurations, measured the same way (device-resident audio, hipEvents);
     parity for each is covered by tests/.  Not part of `value`."""
@@ -234,7 +299,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-session rocprofv3 --pmc traffic measurement")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_child:
+        traffic_child(args.instances, args.device)
+        return
 
     try:
         mode, world = launch_mode(args.gpus, os.environ)
@@ -386,6 +457,16 @@ def main():
             eng.close()
         out["other_configs"] = other_configs(dev, np, FdlEngine, decaying_ir, white_noise)
 
+    if solo and not args.no_pmc:
+        # every engine of this process is closed by now: the child runs need the HBM
+        for eng, _ in engines:
+            eng.close()
+        measured, note = measure_traffic(I, devices[0])
+        if measured is not None:
+            out["roofline"]["traffic"] = measured
+            out["roofline"]["traffic_source"] = note
+        else:
+            out["roofline"]["traffic_source"] = (out["roofline"]["traffic_source"] or "none") + f"; in-session measurement unavailable: {note}"
     if solo and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         out["cpu_baseline_all_cores"] = cpu_baseline_multicore(out["cpu_baseline"], min(4.0, args.cpu_seconds))

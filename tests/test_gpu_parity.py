@@ -511,10 +511,10 @@ def test_bench_workload_kernel_at_full_geometry():
     """The bench workload itself, scaled down in instance count only: mono, B=256, Lh=96000 (P=375, N=512), enough
     instances that the engine picks the non-temporal fused kernel BY ITSELF (working set > 256 MiB), one block per
     call.  Checked against float64 FFT convolution for a few instances and by the linearity checksum over all."""
-    I, B, Lh, T = 512, 256, 96000, 6
+    I, B, Lh, T = 512, 256, 96000, 8
     x1 = white_noise(8000, T * B)
     x = np.broadcast_to(x1, (I, T * B)).copy()
-    with FdlEngine(I, 1, B, Lh, max_blocks_per_call=1) as eng:
+    with FdlEngine(I, 1, B, Lh, max_blocks_per_call=8) as eng:
         assert eng.info.splits == 1 and eng.info.partitions == 375 and eng.info.fft_len == 512
         assert eng.info.device_bytes > (256 << 20)
         hsum, keep = np.zeros(Lh, np.float64), {}
@@ -524,7 +524,13 @@ def test_bench_workload_kernel_at_full_geometry():
             if i in (0, 1, 100, I - 1):
                 keep[i] = h
             eng.set_ir(i, h)
-        y = eng.process(x)
+        # one block per call: k_step_fused<512,2,true>, the bench's timed kernel
+        y = np.concatenate([eng.process(x[:, j * B:(j + 1) * B]) for j in range(T)], axis=1)
+        # the same 8 blocks in ONE call: k_push_fft_batch / k_cmac_tiled<512,8,true> / k_ifft_ola_batch
+        # (bench other_configs "configs[1]_x2048_8_blocks_per_call")
+        eng.reset()
+        y8 = eng.process(x)
+    assert rel_rms(y8, y) < 2e-6
     for i, h in keep.items():
         assert rel_rms(y[i], scipy.signal.fftconvolve(x1.astype(np.float64), h.astype(np.float64))[:T * B]) < RMS_TOL
     assert rel_rms(y.astype(np.float64).sum(axis=0), scipy.signal.fftconvolve(x1.astype(np.float64), hsum)[:T * B]) < RMS_TOL
