@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_bench.json, copied from a real MI355X run) keeps the driver's
+"""The committed bench line (profiles/r02_bench.json, copied from a real MI355X run) keeps the driver's
 contract: required keys, types, and internal consistency of the roofline / cpu_baseline objects."""
 import json
 import os
@@ -7,9 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_spot", "pcie_inclusive"):
         assert k in d, k
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "Msamples/s"
@@ -26,8 +26,24 @@ def test_committed_bench_line_follows_contract():
     per_stream = 8 * d["config"]["partitions"] * d["config"]["fft_len"] + 16 * blk
     assert r["algorithmic_bytes_per_launch"] == inst * per_stream
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert r["traffic_source"] and ("measured by this run" in r["traffic_source"] or "static" in r["traffic_source"])
+    assert d["parity_spot"]["rel_rms_vs_float64"] < d["parity_spot"]["tolerance"] == 1e-5
+    assert d["pcie_inclusive"]["Msamples_per_s"] < d["value"]                 # PCIe-inclusive rate is reported beside, never as, `value`
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Msamples/s" and c["value"] > 0 and c["sample"]
+    assert "-march=native" in c["cflags"]
+    chain = d["other_configs"]["configs[4]_2^20_deconvolve_chain"]
+    assert chain["samples"] == 1 << 20 and chain["deconvolve_default_3x_smoothing_ms"] > chain["deconvolve_no_smoothing_ms"] > 0
+
+
+def test_every_bench_kernel_is_launched_by_a_parity_test():
+    """profiles/r02_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
+    (profiles/collect_r02.py): no kernel is timed that the parity suite does not also run."""
+    lines = open(os.path.join(ROOT, "profiles", "r02_kernel_coverage.txt")).read().strip().splitlines()
+    assert lines[-1] == "bench kernels without a parity-test launch: 0"
+    rows = [l for l in lines[1:-1] if "irb::" in l]
+    assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
+    assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, true" in l for l in rows)
 
 
 def test_launch_mode_never_needs_a_prestarted_world():
