@@ -50,6 +50,7 @@ std::vector<float2> root_table(int root, int count, int stride)      // W_root^(
 struct irb_lfft {
     int device = 0, N = 0, M = 0, M1 = 0, M2 = 0, max_batch = 1, logE = 0;
     int tile_rows = 0;                           // four-step passes: rows/columns per workgroup (0 = one wave per item)
+    int fuse_split = 1;                          // real <-> complex split inside the tiled passes (2 launches instead of 3): bit 0 = inverse, bit 1 = forward
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tabA = nullptr, *d_tabB = nullptr;
@@ -99,16 +100,55 @@ int launch_tile(irb_lfft *p, const irb::LfftArgs &a, const float2 *src, float2 *
         auto k = irb::k_lfft_tile<MX, 4, INV, COLS>;
         if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
         else k<<<dim3(nwg), dim3(irb::kWave * 4), lds, p->stream>>>(a, src, dst);
+    } else if (R == 2) {
+        auto k = irb::k_lfft_tile<MX, 2, INV, COLS>;
+        if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); }
+        else k<<<dim3(nwg), dim3(irb::kWave * 2), lds, p->stream>>>(a, src, dst);
     } else {
         return irb_set_error_(IRB_ERR_ARG, "unsupported tile height");
     }
     return IRB_OK;
 }
 
+// the tiled passes with the real <-> complex split fused in (k_lfft_rows_split / k_lfft_cols_unsplit): FWD = second pass of
+// a forward transform (T -> spectrum), !FWD = first pass of an inverse transform (spectrum -> T)
+template <int MX, bool FWD, bool SETUP = false>
+int launch_fused(irb_lfft *p, const irb::LfftArgs &a, const void *src, void *dst, int nwg)
+{
+    const int R = p->tile_rows;
+    const size_t lds = sizeof(float2) * ((size_t) R * (MX + 1) + irb::TwLds<2 * MX>::SIZE);
+#define IRB_FUSED_CASE(R_)                                                                                                        \
+    if (R == R_) {                                                                                                                \
+        if constexpr (FWD) {                                                                                                      \
+            auto k = irb::k_lfft_rows_split<MX, R_>;                                                                              \
+            if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); } \
+            else k<<<dim3(nwg), dim3(irb::kWave * R_), lds, p->stream>>>(a, static_cast<const float2 *>(src), static_cast<float *>(dst));           \
+        } else {                                                                                                                  \
+            auto k = irb::k_lfft_cols_unsplit<MX, R_>;                                                                            \
+            if (SETUP) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds)); } \
+            else k<<<dim3(nwg), dim3(irb::kWave * R_), lds, p->stream>>>(a, static_cast<const float *>(src), static_cast<float2 *>(dst));           \
+        }                                                                                                                         \
+        return IRB_OK;                                                                                                            \
+    }
+    IRB_FUSED_CASE(4)
+    IRB_FUSED_CASE(8)
+#undef IRB_FUSED_CASE
+    return irb_set_error_(IRB_ERR_ARG, "unsupported tile height for the fused split passes");
+}
+
+bool fused_split(const irb_lfft *p, bool forward)
+{
+    return (p->fuse_split & (forward ? 2 : 1)) && p->M2 > 1 && (p->tile_rows == 4 || p->tile_rows == 8) && p->M1 >= 2 * p->tile_rows;
+}
+
 int setup_tiles(irb_lfft *p)
 {
     if (p->tile_rows <= 0) return IRB_OK;
     const irb::LfftArgs a = {};
+    if (p->M2 > 1 && (p->tile_rows == 4 || p->tile_rows == 8)) {
+        FOR_M(p->M2, { int rc = launch_fused<MM, true, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
+        FOR_M(p->M1, { int rc = launch_fused<MM, false, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
+    }
     FOR_M(p->M1, { int rc = launch_tile<MM, false, true, true>(p, a, nullptr, nullptr, 0); if (rc == IRB_OK) rc = launch_tile<MM, true, true, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
     FOR_M(p->M2, { int rc = launch_tile<MM, false, false, true>(p, a, nullptr, nullptr, 0); if (rc == IRB_OK) rc = launch_tile<MM, true, false, true>(p, a, nullptr, nullptr, 0); if (rc != IRB_OK) return rc; });
     return IRB_OK;
@@ -223,6 +263,10 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
         // workgroups for 256 CUs, so small batches take 4 (32-byte pieces, twice the workgroups: latency-bound anyway)
         p->tile_rows = (long) max_batch * std::min(p->M1, p->M2) / 8 >= 256 ? 8 : 4;
         if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 4, 8, 16
+        // fused split passes (2 launches per transform instead of 3) pay while the transform is launch-bound
+        // (profiles/r02_lfft_fuse_ab.txt): inverse up to 2^20 points, forward (16-byte scattered bin stores) up to 2^18
+        p->fuse_split = (p->N <= (1 << 20) ? 1 : 0) | (p->N <= (1 << 18) ? 2 : 0);
+        if (const char *v = std::getenv("IRB_LFFT_FUSE_SPLIT")) p->fuse_split = std::atoi(v);
         if (p->tile_rows == 16 && std::max(p->M1, p->M2) > 1024) p->tile_rows = 8;
     }
     const int E = 1 << p->logE;
@@ -262,6 +306,13 @@ int irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int b
     if (!p || !d_in || !d_spec) return irb_set_error_(IRB_ERR_ARG, "null argument");
     if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
     HIP_TRY(hipSetDevice(p->device));
+    if (fused_split(p, true)) {                                     // columns pass, then rows pass + split in one launch
+        const irb::LfftArgs a = args_of(p, batch);
+        FOR_M(p->M1, { int rc = launch_tile<MM, false, true>(p, a, reinterpret_cast<const float2 *>(d_in), p->d_w0, batch * (p->M2 / p->tile_rows)); if (rc != IRB_OK) return rc; });
+        FOR_M(p->M2, { int rc = launch_fused<MM, true>(p, a, p->d_w0, d_spec, batch * (p->M1 / p->tile_rows)); if (rc != IRB_OK) return rc; });
+        HIP_TRY(hipGetLastError());
+        return IRB_OK;
+    }
     int rc = complex_fft<false>(p, reinterpret_cast<const float2 *>(d_in), p->d_w0, p->d_w1, batch);
     if (rc != IRB_OK) return rc;
     const long work = (long) batch * (p->M / 2 + 1);
@@ -276,6 +327,14 @@ int irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int 
     if (!p || !d_spec || !d_out) return irb_set_error_(IRB_ERR_ARG, "null argument");
     if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
     HIP_TRY(hipSetDevice(p->device));
+    if (fused_split(p, false)) {                                    // split + columns pass in one launch, then the rows pass (scaled 1/N)
+        irb::LfftArgs a = args_of(p, batch);
+        a.scale = 1.0f / (float) p->N;
+        FOR_M(p->M1, { int rc = launch_fused<MM, false>(p, a, d_spec, p->d_w1, batch * (p->M2 / p->tile_rows)); if (rc != IRB_OK) return rc; });
+        FOR_M(p->M2, { int rc = launch_tile<MM, true, false>(p, a, p->d_w1, reinterpret_cast<float2 *>(d_out), batch * (p->M1 / p->tile_rows)); if (rc != IRB_OK) return rc; });
+        HIP_TRY(hipGetLastError());
+        return IRB_OK;
+    }
     const long work = (long) batch * (p->M / 2 + 1);
     irb::k_rsplit_inv<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(args_of(p, batch), d_spec, p->d_w0);
     HIP_TRY(hipGetLastError());

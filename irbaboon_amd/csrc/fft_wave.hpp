@@ -152,13 +152,22 @@ __device__ __forceinline__ void wave_fft(float2 *buf, const float2 *l_tw, int la
 }
 
 // B real samples (zero padded to N) -> z[n] = x[2n] + i*x[2n+1], n < M, by one wave.
+// All loads (coalesced, clamped instead of predicated) are issued before the first LDS store: one memory latency.
 template <int M>
 __device__ __forceinline__ void wave_load_block(const float *__restrict__ x, int B, float2 *z, int lane)
 {
-    for (int n = lane; n < M; n += kWave) {
-        const int i = 2 * n;
-        z[n] = make_float2(i < B ? x[i] : 0.0f, i + 1 < B ? x[i + 1] : 0.0f);
+    constexpr int N = 2 * M, XL = M >= kWave ? M / kWave : 1;   // B <= M samples: XL per lane
+    float v[XL];
+#pragma unroll
+    for (int i = 0; i < XL; i++) v[i] = x[min(lane + i * kWave, B - 1)];
+    float *zf = reinterpret_cast<float *>(z);                   // z[n] = (x[2n], x[2n+1]): the block as N floats
+#pragma unroll
+    for (int i = 0; i < N / kWave; i++) {
+        const int n = lane + i * kWave;
+        if (i < XL) zf[n] = n < B ? v[i] : 0.0f;
+        else zf[n] = 0.0f;
     }
+    if constexpr (N < kWave) { if (lane < N) zf[lane] = lane < B ? v[0] : 0.0f; }
     wave_sync();
 }
 

@@ -108,16 +108,31 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     const int i0 = g * R;                                    // first column n2 (COLS) / first row k1 (rows)
     const float2 *src = in + b * a.M;
     float2 *dst = out + b * a.M;
-    for (int i = threadIdx.x; i < MX; i += NT) put_twiddle<2 * MX>(l_tw, i, COLS ? a.tw1[i] : a.tw2[i]);
-    if (COLS) {
-        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // x[n1*M2 + n2]: R contiguous n2 per n1
-            const int n1 = idx / R, r = idx % R;
-            tile[r * LD + n1] = src[(size_t) n1 * a.M2 + i0 + r];
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < MX * R; idx += NT) {          // T[k1*M2 + n2]: whole rows
-            const int r = idx / MX, n2 = idx % MX;
-            tile[r * LD + n2] = src[(size_t) (i0 + r) * MX + n2];
+    // every global load of this thread is issued before the first LDS store: one memory latency for the tile (and the
+    // twiddles) instead of one per element -- a `load; store to LDS` loop makes hipcc wait for each load in turn
+    constexpr int EPT = MX >= kWave ? MX / kWave : 1;        // tile elements per thread: MX*R / (64*R)
+    constexpr int TPT = (MX + NT - 1) / NT;                  // twiddle entries per thread
+    float2 twv[TPT], v[EPT];
+    const float2 *twsrc = COLS ? a.tw1 : a.tw2;
+#pragma unroll
+    for (int i = 0; i < TPT; i++) twv[i] = twsrc[min((int) threadIdx.x + i * NT, MX - 1)];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = min((int) threadIdx.x + i * NT, MX * R - 1);   // clamped, not predicated (MX < 64 only)
+        if (COLS) v[i] = src[(size_t) (idx / R) * a.M2 + i0 + idx % R];          // x[n1*M2 + n2]: R contiguous n2 per n1
+        else v[i] = src[(size_t) (i0 + idx / MX) * MX + idx % MX];               // T[k1*M2 + n2]: whole rows
+    }
+#pragma unroll
+    for (int i = 0; i < TPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < MX) put_twiddle<2 * MX>(l_tw, idx, twv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (MX >= kWave || idx < MX * R) {
+            if (COLS) tile[(idx % R) * LD + idx / R] = v[i];
+            else tile[(idx / MX) * LD + idx % MX] = v[i];
         }
     }
     __syncthreads();
@@ -156,6 +171,181 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
             const float2 v = tile[r * LD + k2];
             dst[(size_t) k2 * a.M1 + i0 + r] = make_float2(v.x * a.scale, v.y * a.scale);
         }
+    }
+}
+
+// ---- the real <-> complex split fused into the tiled passes (single launches saved: forward = cols pass + this rows
+// pass, inverse = this cols pass + rows pass) ---------------------------------------------------------------------------
+//
+// forward, second pass: a workgroup takes R rows k1 of T that are closed under the mirror e -> M - e of the split
+// (e = k1 + M1*k2  <->  M - e = (M1 - k1) + M1*(M2 - 1 - k2)): R/2 pairs (p, M1 - p); pair 0 is the two self-mirrored rows
+// (0, M1/2).  Tile slots: r < R/2 -> row P0 + r, r >= R/2 -> the partner of slot R-1-r, so that partner(r) = R-1-r and both
+// halves are ascending runs of adjacent rows (adjacent threads write adjacent bins).  After the row FFTs every bin
+// X[e] = E + W_N^e * O is formed from Z[e] and Z[M-e], both in LDS, and written straight into the spectrum buffer
+// (2N floats per item, bins 0..M, zeros above: the workgroups share the zero fill).
+template <int MX, int R>
+__global__ __launch_bounds__(kWave * R) void k_lfft_rows_split(LfftArgs a, const float2 *__restrict__ in, float *__restrict__ spec)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char l_raw[];
+    constexpr int LD = MX + 1, NT = kWave * R, H = R / 2;
+    constexpr int EPT = MX >= kWave ? MX / kWave : 1, TPT = (MX + NT - 1) / NT;
+    float2 *tile = reinterpret_cast<float2 *>(l_raw);        // [R][LD]
+    float2 *l_tw = tile + R * LD;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int M1 = a.M1, M = a.M;
+    const int groups = M1 / R;                               // (M1/2 pairs) / (R/2 pairs per workgroup)
+    const int g = blockIdx.x % groups;
+    const long b = blockIdx.x / groups;
+    const int P0 = g * H;
+    auto row_of = [&](int r) {
+        const int p = r < H ? P0 + r : P0 + (R - 1 - r);
+        return r < H ? p : (p == 0 ? M1 / 2 : M1 - p);
+    };
+    const float2 *src = in + b * M;
+    float2 *X = reinterpret_cast<float2 *>(spec + b * 2 * a.N);
+
+    float2 twv[TPT], v[EPT];
+#pragma unroll
+    for (int i = 0; i < TPT; i++) twv[i] = a.tw2[min((int) threadIdx.x + i * NT, MX - 1)];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = min((int) threadIdx.x + i * NT, MX * R - 1);
+        v[i] = src[(size_t) row_of(idx / MX) * MX + idx % MX];                       // T[k1*M2 + n2]: whole rows
+    }
+#pragma unroll
+    for (int i = 0; i < TPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < MX) put_twiddle<2 * MX>(l_tw, idx, twv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (MX >= kWave || idx < MX * R) tile[(idx / MX) * LD + idx % MX] = v[i];
+    }
+    __syncthreads();
+    wave_fft<MX, false>(tile + wave * LD, l_tw, lane);
+    __syncthreads();
+
+    // split: thread -> (k2 = idx / R, slot r = idx % R); table loads of all its bins first
+    float2 wa[EPT], wb[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = min((int) threadIdx.x + i * NT, MX * R - 1);
+        const unsigned e = (unsigned) row_of(idx % R) + (unsigned) M1 * (unsigned) (idx / R);
+        wa[i] = a.tabA[e >> a.logE];
+        wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (MX >= kWave || idx < MX * R) {
+            const int r = idx % R, k2 = idx / R, k1 = row_of(r);
+            const int e = k1 + M1 * k2;
+            const bool self = (P0 == 0) && (r == 0 || r == R - 1);       // rows 0 and M1/2 mirror onto themselves
+            const int mr = self ? r : R - 1 - r;
+            const int mc = (self && r == 0) ? (MX - k2) & (MX - 1) : MX - 1 - k2;
+            const float2 p = tile[r * LD + k2], q = tile[mr * LD + mc];
+            if (e == 0) {
+                X[0] = make_float2(p.x + p.y, 0.0f);
+                X[M] = make_float2(p.x - p.y, 0.0f);
+            } else {
+                const float2 ev = make_float2(0.5f * (p.x + q.x), 0.5f * (p.y - q.y));      // (p + conj q)/2
+                const float2 od = make_float2(0.5f * (p.y + q.y), -0.5f * (p.x - q.x));     // (p - conj q)/(2i)
+                X[e] = cadd(ev, cmul(cmul(wa[i], wb[i]), od));
+            }
+        }
+    }
+    // zeros above the Nyquist bin (float2 indices M+1 .. N-1), shared over the workgroups of this item
+    const int per = (M - 1 + groups - 1) / groups;
+    for (int i = threadIdx.x; i < per; i += NT) {
+        const int z = g * per + i;
+        if (z < M - 1) X[M + 1 + z] = make_float2(0.f, 0.f);
+    }
+}
+
+// inverse, first pass: the columns pass reading the SPECTRUM: z[e] = E' + i*O' from X[e] and X[M-e] (plain global
+// loads of the mirrored bin: no pairing constraint), then the column FFTs and the inter-pass factor as k_lfft_tile.
+template <int MX, int R>
+__global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, const float *__restrict__ spec, float2 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char l_raw[];
+    constexpr int LD = MX + 1, NT = kWave * R;
+    constexpr int EPT = MX >= kWave ? MX / kWave : 1, TPT = (MX + NT - 1) / NT;
+    constexpr int CH = EPT < 8 ? EPT : 8;                    // elements per thread per round (4 loads each in flight)
+    float2 *tile = reinterpret_cast<float2 *>(l_raw);
+    float2 *l_tw = tile + R * LD;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int M = a.M, M2 = a.M2;
+    const int groups = M2 / R;
+    const int g = blockIdx.x % groups;
+    const long b = blockIdx.x / groups;
+    const int i0 = g * R;
+    const float2 *X = reinterpret_cast<const float2 *>(spec + b * 2 * a.N);
+    float2 *dst = out + b * M;
+
+    float2 twv[TPT];
+#pragma unroll
+    for (int i = 0; i < TPT; i++) twv[i] = a.tw1[min((int) threadIdx.x + i * NT, MX - 1)];
+#pragma unroll 1
+    for (int c0 = 0; c0 < EPT; c0 += CH) {
+        float2 p[CH], q[CH], wa[CH], wb[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int idx = min((int) threadIdx.x + (c0 + i) * NT, MX * R - 1);
+            const int e = (idx / R) * M2 + i0 + idx % R;                            // x[n1*M2 + n2]: R contiguous n2 per n1
+            p[i] = X[e];
+            q[i] = X[M - e];                                                         // e = 0 reads the Nyquist bin X[M]
+            wa[i] = a.tabA[(unsigned) e >> a.logE];
+            wb[i] = a.tabB[(unsigned) e & ((1u << a.logE) - 1u)];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int idx = threadIdx.x + (c0 + i) * NT;
+            if (MX >= kWave || idx < MX * R) {
+                const int e = (idx / R) * M2 + i0 + idx % R;
+                float2 z;
+                if (e == 0) {
+                    // performRealOnlyInverseTransform rebuilds the negative half from bins 0..N/2 and takes the real
+                    // part of the result: only Re of DC and Nyquist survive
+                    z = make_float2(p[i].x + q[i].x, p[i].x - q[i].x);
+                } else {
+                    const float2 ev = make_float2(p[i].x + q[i].x, p[i].y - q[i].y);        // p + conj q
+                    const float2 d = make_float2(p[i].x - q[i].x, p[i].y + q[i].y);         // p - conj q
+                    const float2 o = cmulc(d, cmul(wa[i], wb[i]));                          // * W_N^{-e}
+                    z = make_float2(ev.x - o.y, ev.y + o.x);
+                }
+                tile[(idx % R) * LD + idx / R] = z;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPT; i++) {
+        const int idx = threadIdx.x + i * NT;
+        if (idx < MX) put_twiddle<2 * MX>(l_tw, idx, twv[i]);
+    }
+    __syncthreads();
+    float2 *mine = tile + wave * LD;
+    wave_fft<MX, true>(mine, l_tw, lane);
+    {
+        const unsigned n2 = (unsigned) (i0 + wave);
+        constexpr int KPL = MX >= kWave ? MX / kWave : 1;
+        float2 wa[KPL], wb[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
+            wa[i] = a.tabA[e >> a.logE];
+            wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
+        }
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const int k1 = lane + i * kWave;
+            if (MX >= kWave || k1 < MX) mine[k1] = cmulc(mine[k1], cmul(wa[i], wb[i]));
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MX * R; idx += NT) {              // T[k1*M2 + n2]
+        const int k1 = idx / R, r = idx % R;
+        dst[(size_t) k1 * M2 + i0 + r] = tile[r * LD + k1];
     }
 }
 

@@ -144,11 +144,14 @@ def test_config5_full_size_default_smoothing_and_inversion():
     assert np.sqrt(np.mean(np.abs(G[band] - R[band]) ** 2) / np.mean(np.abs(R[band]) ** 2)) < 1e-4
 
 
+@pytest.mark.parametrize("fuse", ["0", "3"])
 @pytest.mark.parametrize("tile", ["0", "4", "8", "16"])
-def test_large_fft_tile_heights(monkeypatch, tile):
-    """every tiling of the four-step passes (IRB_LFFT_TILE: rows / columns per workgroup; 0 = one wave per item)
-    gives the same transform: 2^14 .. 2^21 points, batch 1 and 3"""
+def test_large_fft_tile_heights(monkeypatch, tile, fuse):
+    """every tiling of the four-step passes (IRB_LFFT_TILE: rows / columns per workgroup; 0 = one wave per item), with the
+    real split as its own launch or fused into the tiled passes (IRB_LFFT_FUSE_SPLIT: bit 0 inverse, bit 1 forward),
+    gives the same transform: 2^14 .. 2^21 points"""
     monkeypatch.setenv("IRB_LFFT_TILE", tile)
+    monkeypatch.setenv("IRB_LFFT_FUSE_SPLIT", fuse)
     ib.lib().irb_release_cached_plans()
     for n in (1 << 14, 1 << 17, 1 << 20, 1 << 21):
         x = white_noise(n + int(tile), n)
