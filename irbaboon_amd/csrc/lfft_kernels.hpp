@@ -33,6 +33,25 @@ __device__ __forceinline__ float2 big_twiddle(const LfftArgs &a, unsigned e)    
 
 template <int M1> struct WaveGeom { static constexpr int NF = M1 <= 1024 ? 4 : 2; };
 
+// one wave copies M complex values src[n * stride], n < M, into LDS: its global loads go out in batches of up to 8
+// before the LDS stores of the batch (a `load; store to LDS` loop makes hipcc wait for every load in turn)
+template <int M>
+__device__ __forceinline__ void wave_gather(const float2 *__restrict__ src, size_t stride, float2 *l_dst, int lane)
+{
+    constexpr int PL = M >= kWave ? M / kWave : 1, CH = PL < 8 ? PL : 8;
+#pragma unroll 1
+    for (int c0 = 0; c0 < PL; c0 += CH) {
+        float2 v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) v[i] = src[(size_t) min(lane + (c0 + i) * kWave, M - 1) * stride];
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int n = lane + (c0 + i) * kWave;
+            if (M >= kWave || n < M) l_dst[n] = v[i];
+        }
+    }
+}
+
 // ---- pass 1: columns ------------------------------------------------------------------------------
 template <int M1, bool INV>
 __global__ __launch_bounds__(kWave * WaveGeom<M1>::NF) void k_lfft_cols(LfftArgs a, const float2 *__restrict__ in, float2 *__restrict__ out)
@@ -48,7 +67,7 @@ __global__ __launch_bounds__(kWave * WaveGeom<M1>::NF) void k_lfft_cols(LfftArgs
     for (int i = threadIdx.x; i < M1; i += blockDim.x) put_twiddle<2 * M1>(l_tw, i, a.tw1[i]);
     if (live) {
         const float2 *src = in + b * a.M + n2;
-        for (int n1 = lane; n1 < M1; n1 += kWave) l_buf[wave][n1] = src[(size_t) n1 * a.M2];
+        wave_gather<M1>(src, (size_t) a.M2, l_buf[wave], lane);
     }
     __syncthreads();
     if (!live) return;
@@ -76,7 +95,7 @@ __global__ __launch_bounds__(kWave * WaveGeom<M2>::NF) void k_lfft_rows(LfftArgs
     for (int i = threadIdx.x; i < M2; i += blockDim.x) put_twiddle<2 * M2>(l_tw, i, a.tw2[i]);
     if (live) {
         const float2 *src = in + b * a.M + (size_t) k1 * M2;
-        for (int n2 = lane; n2 < M2; n2 += kWave) l_buf[wave][n2] = src[n2];
+        wave_gather<M2>(src, 1, l_buf[wave], lane);
     }
     __syncthreads();
     if (!live) return;
@@ -360,8 +379,7 @@ __global__ __launch_bounds__(kWave * WaveGeom<M>::NF) void k_lfft_small(LfftArgs
     const long b = (long) blockIdx.x * NF + wave;
     const bool live = b < a.batch;
     for (int i = threadIdx.x; i < M; i += blockDim.x) put_twiddle<2 * M>(l_tw, i, a.tw1[i]);
-    if (live)
-        for (int n = lane; n < M; n += kWave) l_buf[wave][n] = in[b * M + n];
+    if (live) wave_gather<M>(in + b * M, 1, l_buf[wave], lane);
     __syncthreads();
     if (!live) return;
     wave_fft<M, INV>(l_buf[wave], l_tw, lane);
