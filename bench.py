@@ -334,8 +334,9 @@ def main():
         devices = [d % ndev for d in range(world)]
 
     I, K, W = args.instances, args.steps, args.warmup
-    engines, xs = [], []
-    for slot, dev in enumerate(devices):
+
+    def build_shard(slot_dev):
+        slot, dev = slot_dev
         shard_id = rank if mode == "ranks" else slot
         eng = FdlEngine(I, 1, B, LH, max_blocks_per_call=NB, device=dev)
         lo = shard_id * I             # weak scaling: every GPU owns I instances of its own, distinct IRs
@@ -343,8 +344,15 @@ def main():
             eng.set_ir(i, decaying_ir(18000 + 2 * (lo + i), LH))
         x = np.stack([white_noise(2000 + 2 * (lo + i), NB * B) for i in range(I)])
         eng.upload(eng.device_io()[0], x)
-        engines.append((eng, lo))
-        xs.append(x)
+        return (eng, lo), x
+
+    if len(devices) > 1:              # one host thread per device for the set-up (one caller thread per handle)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+            built = list(pool.map(build_shard, enumerate(devices)))
+    else:
+        built = [build_shard((0, devices[0]))]
+    engines, xs = [b[0] for b in built], [b[1] for b in built]
     info = engines[0][0].info
 
     # parity spot check on the very kernel that is timed next (every shard; a few instances each)

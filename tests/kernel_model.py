@@ -94,42 +94,56 @@ def cmul_packed(a, c):
     return out
 
 
-# ---- model of fft_wave.hpp: one wave per transform, IN PLACE (all lanes read, then all lanes write),
-# ---- half twiddle table with sign symmetry, split passes that handle bins b and M-b in one lane
+# ---- model of fft_wave.hpp (round 2): one wave per transform, IN PLACE (all lanes read, then all lanes write),
+# ---- LDS twiddle table of 3N/4 entries (host half table + negated first quarter), compile-time unrolled stages with
+# ---- j0 = 4j - 3k, split passes where lane b handles (b, M-b) for b < M/2 and the lane of b = 0 also the bin M/2
 
 def half_table(N):
     return twiddle_table(N)[:N // 2]
 
 
-def tw_half(ht, N, i):
-    w = ht[i & (N // 2 - 1)]
-    return -w if (i & (N // 2)) else w
+def lds_table(ht, N):
+    """what put_twiddle<N> leaves in LDS: W_N^j for j < 3N/4 (entries j + N/2 = -W_N^j for j < N/4)"""
+    t = np.empty(3 * N // 4, np.complex64)
+    t[:N // 2] = ht
+    t[N // 2:] = -ht[:N // 4]
+    return t
 
 
 def wave_fft(buf, ht, N, inverse=False, lanes=64):
     M = len(buf)
+    lt = lds_table(ht, N)
     buf = buf.astype(np.complex64).copy()
     Ns = 1
     while Ns < M:
         R = 4 if Ns * 4 <= M else 2
         nb = M // R
         tstep = N // (Ns * R)
-        reads = {}
-        for lane in range(lanes):                       # phase 1: every lane reads all its points
+        reads, tws = {}, {}
+        for lane in range(lanes):                       # phase 1: every lane reads its points AND its twiddles
             for j in range(lane, nb, lanes):
+                k = j & (Ns - 1)
                 reads[j] = [buf[j + r * nb] for r in range(R)]
+                if R == 4:
+                    assert 3 * k * tstep < len(lt)      # the extended table covers every radix-4 index: no sign fix-up
+                    tws[j] = [lt[k * tstep], lt[2 * k * tstep], lt[3 * k * tstep]]
+                else:
+                    tws[j] = [lt[2 * j]]                # closing radix-2 stage: W_N^(2j), j < M/2
         for j, v in reads.items():                      # phase 2: butterflies + in-place writes
             k = j & (Ns - 1)
             for r in range(1, R):
-                w = tw_half(ht, N, k * r * tstep)
-                v[r] = np.complex64(v[r] * (np.conj(w) if inverse else w))
+                w = tws[j][r - 1]
+                if Ns > 1 or R == 2:
+                    v[r] = np.complex64(v[r] * (np.conj(w) if inverse else w))
             if R == 4:
                 s0, d0, s1, e = v[0] + v[2], v[0] - v[2], v[1] + v[3], v[1] - v[3]
                 d1 = e * (1j if inverse else -1j)
                 o = [s0 + s1, d0 + d1, s0 - s1, d0 - d1]
+                j0 = 4 * j - 3 * k
             else:
                 o = [v[0] + v[1], v[0] - v[1]]
-            j0 = (j - k) * R + k
+                j0 = j
+                assert Ns == M // 2
             for r in range(R):
                 buf[j0 + r * Ns] = np.complex64(o[r])
         Ns *= R
@@ -138,38 +152,60 @@ def wave_fft(buf, ht, N, inverse=False, lanes=64):
 
 def wave_rfft_packed(x, N, ht):
     M = N // 2
+    lt = lds_table(ht, N)
     Z = wave_fft((x[0::2] + 1j * x[1::2]).astype(np.complex64), ht, N)
     X = np.empty(M, np.complex64)
-    for b in range(M // 2 + 1):
+    for b in range(M // 2):                             # b = lane + 64 i < M/2; all reads happen before the stores
+        p, q = Z[b], Z[(M - b) & (M - 1)]
         if b == 0:
-            X[0] = np.complex64(complex(Z[0].real + Z[0].imag, Z[0].real - Z[0].imag))
+            X[0] = np.complex64(complex(p.real + p.imag, p.real - p.imag))
+            X[M // 2] = np.conj(Z[M // 2])              # the self-paired bin, emitted by the lane of b = 0
         else:
-            p, q = Z[b], Z[M - b]
             e = np.complex64(complex(0.5 * (p.real + q.real), 0.5 * (p.imag - q.imag)))
             o = np.complex64(complex(0.5 * (p.imag + q.imag), -0.5 * (p.real - q.real)))
-            t = np.complex64(tw_half(ht, N, b) * o)
+            t = np.complex64(lt[b] * o)
             X[b] = np.complex64(e + t)
-            if b != M - b:
-                X[M - b] = np.complex64(complex(e.real - t.real, t.imag - e.imag))
+            X[M - b] = np.complex64(complex(e.real - t.real, t.imag - e.imag))
     return X
 
 
 def wave_irfft_packed(Y, N, ht):
     M = N // 2
+    lt = lds_table(ht, N)
     Z = Y.astype(np.complex64).copy()
-    for b in range(M // 2 + 1):
+    for b in range(M // 2):
+        p, q = Y[b], Y[(M - b) & (M - 1)]
         if b == 0:
-            Z[0] = np.complex64(complex(Y[0].real + Y[0].imag, Y[0].real - Y[0].imag))
+            Z[0] = np.complex64(complex(p.real + p.imag, p.real - p.imag))
+            Z[M // 2] = np.complex64(2 * np.conj(Y[M // 2]))
         else:
-            p, q = Y[b], Y[M - b]
             e = complex(p.real + q.real, p.imag - q.imag)
             d = np.complex64(complex(p.real - q.real, p.imag + q.imag))
-            o = np.complex64(d * np.conj(tw_half(ht, N, b)))
+            o = np.complex64(d * np.conj(lt[b]))
             Z[b] = np.complex64(complex(e.real - o.imag, e.imag + o.real))
-            if b != M - b:
-                Z[M - b] = np.complex64(complex(e.real + o.imag, o.real - e.imag))
+            Z[M - b] = np.complex64(complex(e.real + o.imag, o.real - e.imag))
     z = wave_fft(Z, ht, N, inverse=True) * np.float32(1.0 / N)
     y = np.empty(N, np.float32)
     y[0::2] = z.real
     y[1::2] = z.imag
     return y
+
+
+# ---- model of k_lfft_rows_split's row pairing (lfft_kernels.hpp): which rows a workgroup owns, and where the mirror
+# ---- M - e of every bin e = k1 + M1*k2 sits in its tile
+
+def rows_split_layout(M1, M2, R):
+    """yields (group, slot r, row k1, k2, mirror slot, mirror column) for every bin, as the kernel computes them"""
+    H = R // 2
+    for g in range(M1 // R):
+        P0 = g * H
+
+        def row_of(r):
+            p = P0 + r if r < H else P0 + (R - 1 - r)
+            return p if r < H else (M1 // 2 if p == 0 else M1 - p)
+        for r in range(R):
+            for k2 in range(M2):
+                self_row = P0 == 0 and r in (0, R - 1)
+                mr = r if self_row else R - 1 - r
+                mc = ((M2 - k2) & (M2 - 1)) if (self_row and r == 0) else M2 - 1 - k2
+                yield g, r, row_of(r), k2, row_of(mr), mc

@@ -27,7 +27,7 @@ def test_model(N):
 
 @pytest.mark.parametrize("N", [32, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_wave_model(N):
-    """fft_wave.hpp: in-place one-wave transform, half twiddle table, paired split passes."""
+    """fft_wave.hpp: in-place one-wave transform, 3N/4-entry LDS twiddle table, paired split passes."""
     from kernel_model import half_table, wave_fft, wave_irfft_packed, wave_rfft_packed
     rng = np.random.default_rng(N + 1)
     ht, M = half_table(N), N // 2
@@ -40,3 +40,17 @@ def test_wave_model(N):
     assert np.abs(X[1:] - R[1:M]).max() < tol
     assert abs(X[0].real - R[0].real) < tol and abs(X[0].imag - R[M].real) < tol
     assert np.abs(wave_irfft_packed(X, N, ht) - x).max() < 2e-6
+
+
+@pytest.mark.parametrize("M1,M2,R", [(64, 64, 4), (64, 128, 8), (512, 1024, 4), (256, 256, 8)])
+def test_fused_split_row_pairing(M1, M2, R):
+    """k_lfft_rows_split: every bin e = k1 + M1*k2 of Z is owned by exactly one workgroup, and the tile position the
+    kernel reads as its mirror really holds Z[M - e] (e = 0 pairs with itself: DC / Nyquist)."""
+    from kernel_model import rows_split_layout
+    M = M1 * M2
+    seen = np.zeros(M, np.int64)
+    for g, r, k1, k2, mk1, mk2 in rows_split_layout(M1, M2, R):
+        e = k1 + M1 * k2
+        seen[e] += 1
+        assert mk1 + M1 * mk2 == (M - e) % M, (g, r, k1, k2)
+    assert np.all(seen == 1)
