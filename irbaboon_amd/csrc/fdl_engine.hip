@@ -58,7 +58,9 @@ struct irb_fdl {
     int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
                                              // `splits` then counts partition splits (workgroups per stream = CS * splits)
     bool fused_deep = false;                 // fused kernel with 8 partitions per stripe in flight (one workgroup per CU)
-    bool cols_sc1 = true;                    // its hand-off: write-through slices (grid <= one workgroup per CU) or fences
+    int cols_handoff = 0;                    // its hand-off (k_step_cols HO): 0 write-through slices + ticket, 1 fences + ticket, 2 tagged granules
+    unsigned long long *d_gran = nullptr;    // [S][splits][N] granules of hand-off form 2
+    unsigned *h_status = nullptr, *d_status = nullptr;   // host-mapped word a kernel raises when a bounded spin gives up
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
     unsigned flags = 0;
@@ -112,7 +114,7 @@ int env_int(const char *name, int dflt)
 void choose_path(irb_fdl *h)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
-    h->colW = 0; h->splits = 1; h->cols_sc1 = true;
+    h->colW = 0; h->splits = 1; h->cols_handoff = 0;
     if (h->flags & IRB_FDL_FORCE_FUSED) return;
     if (h->flags & IRB_FDL_FORCE_SPLIT) {
         // measured optimum of that kernel: 16..64 workgroups per stream with >= 16 partitions per stripe
@@ -154,8 +156,13 @@ void choose_path(irb_fdl *h)
     PS = std::max(1, env_int("IRB_PSPLITS", PS));
     h->colW = W;
     h->splits = PS;
-    // write-through (sc1) slices: no release/acquire fence.  IRB_COLS_SC1=0 selects the fenced form (A/B, tests).
-    h->cols_sc1 = env_int("IRB_COLS_SC1", 1) != 0;
+    // hand-off form: tagged granules while the whole grid is certainly resident (<= 256 workgroups: the reducer spins),
+    // else write-through slices + ticket; IRB_COLS_HANDOFF=0|1|2 overrides (1 = release/acquire fences: A/B, tests)
+    // (measured, profiles/r02_handoff_ab.txt: granules win on narrow slices -- 1 to 8 streams: 5.41 -> 5.15, 7.29 -> 6.39,
+    // 7.18 -> 6.65 us -- and lose from 32 streams on, where one reducer per stream sweeps 2048+ granules)
+    h->cols_handoff = env_int("IRB_COLS_HANDOFF", (base * PS <= 256 && W < 64) ? 2 : 0);
+    if (env_int("IRB_COLS_SC1", 1) == 0) h->cols_handoff = 1;                 // older spelling of the fenced form
+    if (h->cols_handoff < 0 || h->cols_handoff > 2) h->cols_handoff = 0;
 }
 
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
@@ -182,20 +189,31 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
     a.B = h->B; a.P = h->Ppad; a.R = h->R; a.head = (int) (h->t % h->R); a.splits = h->splits;
+    a.gran = h->d_gran; a.status = h->d_status; a.epoch = (unsigned) (h->t % 0xFFFFFFFFull) + 1u;
     return a;
 }
 
-#define LAUNCH_COLS(W_, SC1_)                                                                                    \
-    FOR_N(h->N, irb::k_step_cols<NN, W_, SC1_><<<dim3(h->S * irb::ColsGeom<NN, W_>::CS * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets))
+#define LAUNCH_COLS(W_, HO_)                                                                                     \
+    FOR_N(h->N, irb::k_step_cols<NN, W_, HO_><<<dim3(h->S * irb::ColsGeom<NN, W_>::CS * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets))
+#define LAUNCH_COLS_W(HO_)                                                                                        \
+    if (h->colW == 4) { LAUNCH_COLS(4, HO_); } else if (h->colW == 16) { LAUNCH_COLS(16, HO_); } else { LAUNCH_COLS(64, HO_); }
 
 int launch_cols(irb_fdl *h, const irb::StepArgs &a)
 {
-    if (h->cols_sc1) {
-        if (h->colW == 4) { LAUNCH_COLS(4, true); } else if (h->colW == 16) { LAUNCH_COLS(16, true); } else { LAUNCH_COLS(64, true); }
-    } else {
-        if (h->colW == 4) { LAUNCH_COLS(4, false); } else if (h->colW == 16) { LAUNCH_COLS(16, false); } else { LAUNCH_COLS(64, false); }
-    }
+    if (h->cols_handoff == 2) { LAUNCH_COLS_W(2) }
+    else if (h->cols_handoff == 1) { LAUNCH_COLS_W(1) }
+    else { LAUNCH_COLS_W(0) }
     HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+// a kernel's bounded spin gave up (hand-off form 2): report it once, at the next point where the host has waited
+int check_status(irb_fdl *h)
+{
+    if (h->h_status && *h->h_status) {
+        *h->h_status = 0;
+        return fail(IRB_ERR_STATE, "in-kernel hand-off timed out (a producer workgroup never published its slice)");
+    }
     return IRB_OK;
 }
 
@@ -285,7 +303,8 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
-    (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets);
+    (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
+    if (h->h_status) (void) hipHostFree(h->h_status);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
@@ -355,15 +374,19 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (!guard(dev_alloc(h, &h->d_irtime, (size_t) h->C * h->P * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_stream_info, (size_t) h->S))) break;
         if (!guard(dev_alloc(h, &h->d_tickets, (size_t) h->S))) break;
+        if (h->colW > 0 && !guard(dev_alloc(h, &h->d_gran, (size_t) h->S * h->splits * h->N))) break;
         hipError_t e;
         if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) h->S * h->Tmax * h->B)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_set_of_stream), sizeof(int) * h->S)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess ||
-            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info), sizeof(int2) * h->S)) != hipSuccess) {
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info), sizeof(int2) * h->S)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_status), sizeof(unsigned), hipHostMallocMapped)) != hipSuccess ||
+            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_status), h->h_status, 0)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
             break;
         }
+        *h->h_status = 0;
         // twiddles: W_N^j in double, rounded to float
         std::vector<float2> tw(h->N);
         for (int j = 0; j < h->N; j++) {
@@ -375,6 +398,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * (size_t) h->S, h->stream)) != hipSuccess ||
+            (h->d_gran && (e = hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream)) != hipSuccess) ||
             (e = hipMemsetAsync(h->d_in, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_out, 0, sizeof(float) * (size_t) h->S * h->Tmax * h->B, h->stream)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "device init: %s", hipGetErrorString(e));
@@ -513,6 +537,8 @@ int irb_fdl_reset(irb_fdl *h)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream));
+    if (h->d_gran)                                  // the step counter restarts, and with it the granule tags
+        HIP_TRY(hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream));
     h->t = 0;
     h->ovl_cur = 0;
     return IRB_OK;
@@ -540,7 +566,7 @@ int irb_fdl_synchronize(irb_fdl *h)
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return IRB_OK;
+    return check_status(h);
 }
 
 // one chunk (nb <= Tmax blocks starting at block `done`) of the host-pointer call, split so that several handles
@@ -565,7 +591,7 @@ static int process_chunk_end(irb_fdl *h, float *const *out, int done, int nb)
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) nb * h->B;
     for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, h->h_io + (size_t) s * stride, sizeof(float) * n);
-    return IRB_OK;
+    return check_status(h);
 }
 
 int irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks)
@@ -599,6 +625,8 @@ int irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride,
         HIP_TRY(hipMemcpy2DAsync(out + (size_t) done * h->B, sizeof(float) * stride, h->d_out, sizeof(float) * dstride, width, h->S,
                                  hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        rc = check_status(h);
+        if (rc != IRB_OK) return rc;
     }
     return IRB_OK;
 }

@@ -47,6 +47,9 @@ struct StepArgs {
     const float  *in;           // block j of stream s at in + s*in_stride + j*B
     float        *out;
     float2       *part;         // [S][splits][M] partial sums (split path)
+    unsigned long long *gran;   // [S][splits][2M] tagged granules {epoch : value} of the granule hand-off (k_step_cols<.., 2>)
+    unsigned     *status;       // host-visible word: set to 1 if a granule wait gave up (bounded spin)
+    unsigned      epoch;        // tag of this launch's granules: step counter + 1, never 0
     long          in_stride, out_stride;
     int           B, P, R, head, splits;
     // time-tiled path (several blocks per call)
@@ -720,9 +723,20 @@ struct ColsGeom {
 //   * every other wave ("loader"): its stripe of the partition range, U rows of H and of the FDL per thread per
 //     round, unconditional 16-byte loads; wave 0 of the other workgroups also stages the twiddles and prefetches
 //     the overlap, because ANY workgroup can turn out to be the last arriver that runs the inverse FFT.
-template <int N, int W_, bool SC1, int U = 8>
+// Hand-off forms of k_step_cols (HO):
+//   0  write-through (sc1) slices + drained wait + ONE ticket per workgroup; the last arriver finishes the stream
+//   1  plain slices + agent-scope release / acquire fences around the ticket (the textbook form; A/B and tests)
+//   2  tagged granules (cdna_hip_programming.md Guideline 16, R2: "the data is the flag"): every float of a slice is
+//      ONE aligned 8-byte sc1 store {tag = epoch, value}; a producer exits right after issuing them -- no drain, no
+//      barrier, no ticket.  The workgroup (slice 0, range 0) of each stream is the reducer: it re-reads the stream's
+//      granules with sc1 loads until every tag equals this launch's epoch (bounded spin: on a 50 ms timeout it raises
+//      a.status and carries on, so a lost producer cannot hang the grid).  Two memory round trips (the producers'
+//      store, the reducer's sweep) instead of four (store drain, ticket, slice loads + their barriers).  All
+//      workgroups of the grid must be able to run while the reducer spins: the host uses it for grids <= 256 only.
+template <int N, int W_, int HO, int U = 8>
 __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__restrict__ tickets)
 {
+    constexpr bool SC1 = (HO == 0);
     using C = ColsGeom<N, W_>;
     constexpr int M = C::M, W = C::W, CS = C::CS, TWL = C::TWL, NWAVES = kThreads / kWave;
     __shared__ float2 l_tw[TwLds<N>::SIZE];
@@ -753,7 +767,8 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     float2 dc = make_float2(0.f, 0.f);
     BlockIo<N> io;                                     // wave 0: new block + saved overlap (prefetched: any workgroup may run the tail)
     float2 twr[TWL];
-    if (wave == 0) {                                   // loads are clamped, never lane-predicated (see BlockIo)
+    const bool may_finish = HO != 2 || (cs == 0 && ps == 0);   // granule form: the reducer is known in advance
+    if (wave == 0 && (first || may_finish)) {          // loads are clamped, never lane-predicated (see BlockIo)
 #pragma unroll
         for (int i = 0; i < TWL; i++) twr[i] = a.tw[min(lane + i * kWave, N / 2 - 1)];
         io.load(a.in + (size_t) s * a.in_stride, a.ovl + (size_t) s * a.B, a.B, lane);
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         issue(k);
         __builtin_amdgcn_sched_barrier(0);
         IRB_STAMP(a, 1);
-        if (wave == 0) {                               // twiddles for a possible inverse FFT later (this wave's own use)
+        if (wave == 0 && may_finish) {                 // twiddles for a possible inverse FFT later (this wave's own use)
 #pragma unroll
             for (int i = 0; i < TWL; i++) {
                 const int idx = lane + i * kWave;
@@ -873,8 +888,70 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         const int b = 2 * (cs * W + tid);
         const float2 lo = b == 0 ? d : make_float2(t.x, t.y);       // packed bin 0: two real products
         const float2 hi = make_float2(t.z, t.w);
-        if constexpr (SC1) { st_sc1(slab + b, lo); st_sc1(slab + b + 1, hi); }
+        if constexpr (HO == 2) {
+            unsigned long long *g = a.gran + ((size_t) s * PS + ps) * (2 * M) + 2 * b;     // one granule per float
+            const unsigned long long tag = (unsigned long long) a.epoch << 32;
+            __hip_atomic_store(g + 0, tag | __float_as_uint(lo.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, tag | __float_as_uint(lo.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 2, tag | __float_as_uint(hi.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 3, tag | __float_as_uint(hi.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if constexpr (SC1) { st_sc1(slab + b, lo); st_sc1(slab + b + 1, hi); }
         else *reinterpret_cast<float4 *>(slab + b) = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+
+    if constexpr (HO == 2) {
+        if (!may_finish) return;                       // producer: done (its granule stores complete on their own)
+        // ---- reducer: sweep the stream's granules until every tag is this launch's epoch, summing the PS rows ----
+        const unsigned long long *rows = a.gran + (size_t) s * PS * (2 * M);
+        float *yf = reinterpret_cast<float *>(l_buf);
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+        bool gave_up = false;
+        // this thread's floats f = tid + 256 i, i < FPT, of every row r < PS: items q = r * FPT + i, swept 8 at a time
+        // (all loads of a sweep in flight together; a sweep repeats until its 8 tags match)
+        constexpr int FPT = N >= kThreads ? N / kThreads : 1;
+        float v[FPT];
+#pragma unroll
+        for (int i = 0; i < FPT; i++) v[i] = 0.0f;
+        const int items = FPT * PS;
+        for (int q0 = 0; q0 < items; q0 += 8) {
+            unsigned long long g[8];
+            for (;;) {
+                bool ready = true;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int q = q0 + j, f = tid + (q % FPT) * kThreads;
+                    if (q < items && f < 2 * M) {
+                        g[j] = __hip_atomic_load(rows + (size_t) (q / FPT) * (2 * M) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && (unsigned) (g[j] >> 32) == a.epoch;
+                    } else {
+                        g[j] = 0;                          // absent item: adds +0
+                    }
+                }
+                if (ready) break;
+                if (__builtin_amdgcn_s_memrealtime() - t_start > 5000000ull) { gave_up = true; break; }   // 50 ms
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = (q0 + j) % FPT;
+#pragma unroll
+                for (int ii = 0; ii < FPT; ii++)           // static register index
+                    if (ii == i) v[ii] += __uint_as_float((unsigned) g[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FPT; i++) {
+            const int f = tid + i * kThreads;
+            if (f < 2 * M) yf[f] = v[i];
+        }
+        if (gave_up) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (wave == 0) {
+            wave_split_inverse<M>(l_buf, l_tw, lane);
+            wave_fft<M, true>(l_buf, l_tw, lane);
+            io.overlap_add(l_buf, a.B, a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
+        }
+        return;
     }
 
     // ---- publish: drained stores, barrier, (plain-store form: one agent-scope release), one ticket ----

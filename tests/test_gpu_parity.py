@@ -612,17 +612,19 @@ def test_bench_multi_gpu_code_path_rehearsal():
     assert abs(d["value"] - 2 * 512 * 256 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
 
 
-@pytest.mark.parametrize("w,sc1,ps", [(4, 1, 1), (4, 1, 5), (4, 0, 3), (16, 1, 2), (16, 0, 1), (64, 1, 1), (64, 0, 4), (64, 1, 7)])
+@pytest.mark.parametrize("w,ho,ps", [(4, 0, 1), (4, 2, 1), (4, 0, 5), (4, 2, 5), (4, 1, 3), (16, 0, 2), (16, 2, 2), (16, 2, 16), (16, 1, 1),
+                                     (64, 0, 1), (64, 2, 1), (64, 1, 4), (64, 0, 7), (64, 2, 7)])
 @pytest.mark.parametrize("case", [(1, 1, 1, 256, 9000, 20), (2, 2, 2, 128, 5000, 24), (3, 1, 1, 512, 9000, 9), (1, 2, 1, 64, 700, 30),
                                   (2, 1, 1, 1024, 9000, 7), (1, 1, 1, 16, 100, 40), (2, 1, 1, 100, 950, 21)],
                          ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
-def test_column_sliced_step_variants(monkeypatch, case, w, sc1, ps):
+def test_column_sliced_step_variants(monkeypatch, case, w, ho, ps):
     """k_step_cols in every shape the engine can choose: slice widths 4 / 16 / 64 float4 columns (clamped to the row
-    for small N), write-through (sc1) and release/acquire hand-off, 1..7 partition splits (also more splits than
-    partitions per stripe, ranges that need several load rounds, and empty ranges)."""
+    for small N); the three hand-off forms (0 write-through slices + ticket, 1 release/acquire fences + ticket,
+    2 tagged granules swept by a fixed reducer); 1..16 partition splits (also more splits than partitions per stripe,
+    ranges that need several load rounds, and empty ranges)."""
     I, C, Cir, B, Lh, T = case
     monkeypatch.setenv("IRB_COLW", str(w))
-    monkeypatch.setenv("IRB_COLS_SC1", str(sc1))
+    monkeypatch.setenv("IRB_COLS_HANDOFF", str(ho))
     monkeypatch.setenv("IRB_PSPLITS", str(ps))
     x = _streams(I, C, T * B, 9100)
     irs = [np.stack([decaying_ir(9200 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
@@ -631,7 +633,7 @@ def test_column_sliced_step_variants(monkeypatch, case, w, sc1, ps):
             eng.set_ir(i, irs[i])
         y = eng.process(x)
         eng.reset()
-        assert np.array_equal(eng.process(x), y)          # deterministic: no atomics in the sums, tickets re-armed
+        assert np.array_equal(eng.process(x), y)          # deterministic: no atomics in the sums; tickets / granule tags re-armed
     for i in range(I):
         ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
         for c in range(C):

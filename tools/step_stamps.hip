@@ -32,13 +32,13 @@ static void launch(const std::string &mode, irb::StepArgs a, unsigned *tickets, 
         irb::k_step_fused<N, 2, false><<<dim3(S), dim3(irb::kThreads)>>>(a);
     } else if (W == 4) {
         *grid_out = S * irb::ColsGeom<N, 4>::CS * PS;
-        irb::k_step_cols<N, 4, true><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
+        irb::k_step_cols<N, 4, 0><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
     } else if (W == 16) {
         *grid_out = S * irb::ColsGeom<N, 16>::CS * PS;
-        irb::k_step_cols<N, 16, true><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
+        irb::k_step_cols<N, 16, 0><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
     } else {
         *grid_out = S * irb::ColsGeom<N, 64>::CS * PS;
-        irb::k_step_cols<N, 64, true><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
+        irb::k_step_cols<N, 64, 0><<<dim3(*grid_out), dim3(irb::kThreads)>>>(a, tickets);
     }
 }
 
