@@ -77,7 +77,7 @@ def main():
               open(os.path.join(HERE, "hbm_traffic.json"), "w"))
     # latency kernels: where the wave cycles go
     lat = {}
-    for tag, name in (("lat1", "configs[1] single stream: k_step_cols<512,4,true>"), ("lat2", "configs[2] stereo 10 s IR: k_step_cols<256,4,true>")):
+    for tag, name in (("lat1", "configs[1] single stream: k_step_cols<512,4,2>"), ("lat2", "configs[2] stereo 10 s IR: k_step_cols<256,4,2>")):
         cc = {}
         for d in glob.glob(os.path.join(P, tag + "_*")):
             if os.path.isdir(d) and not d.endswith("_kt"):

@@ -43,7 +43,7 @@ def test_every_bench_kernel_is_launched_by_a_parity_test():
     assert lines[-1] == "bench kernels without a parity-test launch: 0"
     rows = [l for l in lines[1:-1] if "irb::" in l]
     assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
-    assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, true" in l for l in rows)
+    assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, 2" in l for l in rows)
 
 
 def test_launch_mode_never_needs_a_prestarted_world():
