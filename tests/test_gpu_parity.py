@@ -684,3 +684,30 @@ def test_column_sliced_handoff_under_uneven_load():
         stop.set()
         th.join()
     assert max(res) < 2e-6, res
+
+
+@pytest.mark.parametrize("ho", ["0", "2"])
+@pytest.mark.parametrize("geom", [(1, 1, 256, 96000), (1, 2, 128, 60000), (8, 1, 256, 24000)], ids=lambda g: "I%d_C%d_B%d_Lh%d" % g)
+def test_back_to_back_steps_without_host_sync(monkeypatch, geom, ho):
+    """The bench's launch pattern: one-block steps enqueued back to back on the engine's stream, audio resident in HBM,
+    no host synchronisation in between (launch k+1 is only stream-ordered behind launch k: tickets re-armed / granule
+    tags advanced by the kernels themselves).  96 steps, then one download, vs float64 FFT convolution."""
+    I, C, B, Lh = geom
+    T = 96
+    monkeypatch.setenv("IRB_COLS_HANDOFF", ho)
+    x = _streams(I, C, T * B, 8800)
+    irs = [np.stack([decaying_ir(8900 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=T, flags=_lib.FORCE_COLS) as eng:
+        for i in range(I):
+            eng.set_ir(i, irs[i])
+        d_in, d_out, stride = eng.device_io()
+        assert stride == T * B
+        eng.upload(d_in, x)
+        for j in range(T):
+            eng.process_device(d_in + j * B * 4, d_out + j * B * 4, stride, 1)
+        eng.synchronize()
+        y = eng.download(d_out, I * C * stride).reshape(I * C, stride)
+    for i in range(I):
+        for c in range(C):
+            ref = scipy.signal.fftconvolve(x[i * C + c].astype(np.float64), irs[i][c].astype(np.float64))[:T * B]
+            assert rel_rms(y[i * C + c], ref) < RMS_TOL
