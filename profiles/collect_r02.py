@@ -38,8 +38,12 @@ def kernel_names(path):
 def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(HERE), "gpurun_out")
     P = os.path.join(out_dir, "prof_r02")
-    # kernel traces
-    for src, dst in (("bench_kt", "r02_bench_default_kernel_stats.csv"), ("tests_kt", "r02_gputest_kernel_stats.csv"),
+    # kernel traces (the bench's trace preferably from tools/bench_and_trace.sh: same device as the committed bench line)
+    pair = os.path.join(out_dir, "bench_pair")
+    if os.path.exists(os.path.join(pair, "bench.json")):
+        shutil.copy(os.path.join(pair, "bench.json"), os.path.join(HERE, "r02_bench.json"))
+        shutil.copy(os.path.join(pair, "bench_under_trace.json"), os.path.join(HERE, "r02_bench_under_trace.json"))
+    for src, dst in ((os.path.join("..", "bench_pair", "kt") if os.path.exists(os.path.join(pair, "kt")) else "bench_kt", "r02_bench_default_kernel_stats.csv"), ("tests_kt", "r02_gputest_kernel_stats.csv"),
                      ("lat1_kt", "r02_single_stream_kernel_stats.csv"), ("lat2_kt", "r02_cfg3_streaming_kernel_stats.csv"),
                      ("lfft_kt", "r02_lfft_kernel_stats.csv")):
         f = stats_csv(os.path.join(P, src))
