@@ -71,13 +71,31 @@ __global__ __launch_bounds__(256) void k_linear(const v4f *__restrict__ a, float
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
 }
-int main()
+// fills a buffer with pseudo-random floats in [-1, 1): DRAM power, and with it the clocks the chip sustains, depend on
+// the DATA (MI355X_MICROARCH.md, DVFS: zero-filled inputs ran 19 % faster in a GEMM), so the ceiling must be measured
+// on data like the spectra the real kernel streams, not on zeros
+__global__ void k_fill(float *p, size_t n, unsigned seed)
 {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (float) ((long long) (z >> 40) - (1 << 23)) / (float) (1 << 23);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const bool zeros = argc > 1 && argv[1][0] == 'z';
     const int S = 2048, rows = 375 * 128;            // 375 rows of 2 KB = 128 float4
     const size_t n = (size_t) S * rows;
     v4f *a, *b; float *o;
     hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&o, S * 4);
-    hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 16);
+    if (zeros) { hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 16); }
+    else { k_fill<<<4096, 256>>>((float *) a, n * 4, 1u); k_fill<<<4096, 256>>>((float *) b, n * 4, 77u); }
+    hipDeviceSynchronize();
+    printf("data: %s\n", zeros ? "all zeros" : "pseudo-random floats in [-1, 1)");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](auto kern, const char *name) {
         for (int i = 0; i < 5; i++) kern<<<S, 256>>>(a, b, o, rows);
