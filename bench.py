@@ -325,6 +325,10 @@ def main():
     rehearsal = None
     if mode == "ranks":
         devices = [ranks.local_rank % ndev]
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if local_world > ndev:
+            rehearsal = (f"{local_world} ranks on {ndev} device(s) (gloo for the barrier): a rehearsal of the multi-rank code path, "
+                         f"not a scaling measurement")
     else:
         if world > ndev:
             if os.environ.get("IRB_BENCH_SHARE_DEVICE") != "1":
