@@ -1,0 +1,56 @@
+"""Randomised campaign over every one-block step path and its knobs (not part of the test suite: minutes of GPU time).
+Random engine shapes, IR lengths, call sizes, hand-off forms and slice widths; every output against float64 FFT convolution.
+usage: python tools/fuzz_paths.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.signal
+from irbaboon_amd import FdlEngine, _lib
+from irbaboon_amd.synth import decaying_ir, white_noise
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0, n, worst = time.time(), 0, 0.0
+counts = {}
+while time.time() - t0 < budget:
+    I = int(rng.choice([1, 1, 2, 3, 5, 9, 17, 40]))
+    C = int(rng.integers(1, 3))
+    B = int(rng.choice([8, 16, 32, 64, 100, 128, 256, 512, 1024, 2048]))
+    cap = int(rng.integers(1, 40)) * B + int(rng.integers(0, B))
+    Lh = int(rng.integers(1, cap + 1))
+    T = int(rng.integers(1, 14))
+    tmax = int(rng.choice([1, 1, 1, 3, 8]))
+    flags = int(rng.choice([0, _lib.FORCE_COLS, _lib.FORCE_COLS, _lib.FORCE_FUSED, _lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH]))
+    env = {}
+    if flags == _lib.FORCE_COLS:
+        env = {"IRB_COLW": str(rng.choice([4, 16, 64])), "IRB_COLS_HANDOFF": str(rng.choice([0, 1, 2])), "IRB_PSPLITS": str(rng.integers(1, 17))}
+    for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ir_ch = int(rng.integers(1, 3))
+    x = np.stack([white_noise(int(rng.integers(1 << 30)), T * B) for _ in range(I * C)])
+    irs = [np.stack([decaying_ir(int(rng.integers(1 << 30)), Lh) for _ in range(ir_ch)]) for _ in range(I)]
+    with FdlEngine(I, C, B, cap, max_blocks_per_call=tmax, flags=flags) as eng:
+        for i in range(I):
+            eng.set_ir(i, irs[i])
+        # split the T blocks into random calls
+        y, j = [], 0
+        while j < T:
+            nb = int(rng.integers(1, T - j + 1))
+            y.append(eng.process(x[:, j * B:(j + nb) * B]))
+            j += nb
+        y = np.concatenate(y, axis=1)
+        key = (flags, eng.info.splits > 1)
+    counts[key] = counts.get(key, 0) + 1
+    for i in range(I):
+        for c in range(C):
+            if ir_ch == 2 and C == 1:
+                h = ((irs[i][0].astype(np.float32) + irs[i][1]) / np.float32(2)).astype(np.float64)
+            else:
+                h = irs[i][c if (ir_ch == C) else 0].astype(np.float64)
+            ref = scipy.signal.fftconvolve(x[i * C + c].astype(np.float64), h)[:T * B]
+            den = np.sqrt(np.mean(ref ** 2))
+            err = np.sqrt(np.mean((y[i * C + c] - ref) ** 2)) / den if den > 0 else np.abs(y[i * C + c]).max()
+            worst = max(worst, err)
+            assert err < 1e-5, (I, C, B, cap, Lh, T, tmax, flags, env, i, c, err)
+    n += 1
+print(f"{n} random engines in {time.time()-t0:.0f} s, worst rel RMS {worst:.2e}; by (flags, multi-workgroup): {counts}")
