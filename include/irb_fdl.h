@@ -46,6 +46,8 @@ extern "C" {
 #define IRB_FDL_SPLIT_3LAUNCH 0x4u  /* split path as three launches (no in-kernel hand-off) */
 #define IRB_FDL_NO_PAIRING    0x8u  /* never share IR rows between the two channels of an instance */
 #define IRB_FDL_FORCE_COLS    0x10u /* always the column-sliced single-launch step (k_step_cols)   */
+#define IRB_FDL_HOST_IO       0x20u /* irb_fdl_process / set_ir_partition: kernels read and write mapped pinned host memory directly
+                                       (zero copy; for small real-time engines: one launch + one wait per block, no copy round trips) */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */

@@ -71,8 +71,12 @@ struct irb_fdl {
     float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
     int2 *d_stream_info = nullptr;          // [S] {IR set, partitions in use}: what the kernels read
     unsigned *d_tickets = nullptr;           // [S] arrival counters of k_step_split
-    float *h_io = nullptr;                   // pinned: [S][Tmax*B]
+    float *h_io = nullptr;                   // pinned: [S][Tmax*B]  (IRB_FDL_HOST_IO: [2][S][Tmax*B], input half + output half)
     float *h_ir = nullptr;                   // pinned: [C][P*B]
+    // IRB_FDL_HOST_IO: the kernels read blocks / IR partitions from, and write output blocks to, MAPPED pinned host memory
+    // (zero copy): a blocking process call is pack + launch + wait, with no copy-engine round trips
+    bool host_io = false;
+    float *d_hio = nullptr, *d_hir = nullptr;   // device addresses of h_io / h_ir
     int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // host: IR set of every stream, partitions in use of every set
     int2 *h_info = nullptr;                  // pinned staging of d_stream_info
 };
@@ -376,8 +380,12 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (!guard(dev_alloc(h, &h->d_tickets, (size_t) h->S))) break;
         if (h->colW > 0 && !guard(dev_alloc(h, &h->d_gran, (size_t) h->S * h->splits * h->N))) break;
         hipError_t e;
-        if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) h->S * h->Tmax * h->B)) != hipSuccess ||
-            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B)) != hipSuccess ||
+        h->host_io = (h->flags & IRB_FDL_HOST_IO) != 0;
+        const unsigned hflags = h->host_io ? hipHostMallocMapped : hipHostMallocDefault;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) (h->host_io ? 2 : 1) * h->S * h->Tmax * h->B, hflags)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B, hflags)) != hipSuccess ||
+            (h->host_io && (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hio), h->h_io, 0)) != hipSuccess) ||
+            (h->host_io && (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hir), h->h_ir, 0)) != hipSuccess) ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_set_of_stream), sizeof(int) * h->S)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info), sizeof(int2) * h->S)) != hipSuccess ||
@@ -478,8 +486,13 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
     float *hs = h->h_ir + (size_t) partition * h->B;
     float *ds = h->d_irtime + (size_t) partition * h->B;
     std::memcpy(hs, samples, sizeof(float) * h->B);
-    HIP_TRY(hipMemcpyAsync(ds, hs, sizeof(float) * h->B, hipMemcpyHostToDevice, h->stream));
-    int rc = launch_ir_fft(h, ds, 1, 1, first_set, partition);
+    int rc;
+    if (h->host_io) {
+        rc = launch_ir_fft(h, h->d_hir + (size_t) partition * h->B, 1, 1, first_set, partition);     // the kernel reads the pinned staging itself
+    } else {
+        HIP_TRY(hipMemcpyAsync(ds, hs, sizeof(float) * h->B, hipMemcpyHostToDevice, h->stream));
+        rc = launch_ir_fft(h, ds, 1, 1, first_set, partition);
+    }
     if (rc != IRB_OK) return rc;
     bool changed = false;
     for (int c = 0; c < h->C; c++) {
@@ -577,6 +590,8 @@ static int process_chunk_begin(irb_fdl *h, const float *const *in, int done, int
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) nb * h->B;
     for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
+    if (h->host_io)                                   // zero copy: input half -> kernels -> output half, both in mapped host memory
+        return irb_fdl_process_device(h, h->d_hio, h->d_hio + (size_t) h->S * stride, stride, nb);
     HIP_TRY(hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
     int rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
     if (rc != IRB_OK) return rc;
@@ -587,10 +602,11 @@ static int process_chunk_begin(irb_fdl *h, const float *const *in, int done, int
 static int process_chunk_end(irb_fdl *h, float *const *out, int done, int nb)
 {
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));      // (polling hipStreamQuery instead was measured: no gain)
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) nb * h->B;
-    for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, h->h_io + (size_t) s * stride, sizeof(float) * n);
+    const float *res = h->h_io + (h->host_io ? (size_t) h->S * stride : 0);
+    for (int s = 0; s < h->S; s++) std::memcpy(out[s] + (size_t) done * h->B, res + (size_t) s * stride, sizeof(float) * n);
     return check_status(h);
 }
 

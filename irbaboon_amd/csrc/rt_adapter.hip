@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -112,6 +113,8 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     std::memset(&cfg, 0, sizeof cfg);
     cfg.device = p->device; cfg.n_instances = 1; cfg.channels = p->C; cfg.block = p->B;
     cfg.max_ir_len = p->P * p->B; cfg.max_blocks_per_call = 1;
+    cfg.flags = IRB_FDL_HOST_IO;          // one block per callback: kernels read / write the pinned staging directly (no copy round trips)
+    if (const char *v = std::getenv("IRB_RT_HOST_IO")) { if (std::atoi(v) == 0) cfg.flags = 0; }     // A/B
     return irb_fdl_create(&cfg, &p->eng);
 }
 

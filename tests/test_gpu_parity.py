@@ -711,3 +711,28 @@ def test_back_to_back_steps_without_host_sync(monkeypatch, geom, ho):
         for c in range(C):
             ref = scipy.signal.fftconvolve(x[i * C + c].astype(np.float64), irs[i][c].astype(np.float64))[:T * B]
             assert rel_rms(y[i * C + c], ref) < RMS_TOL
+
+
+@pytest.mark.parametrize("case", [(1, 2, 256, 2048, 12, 1), (2, 1, 128, 3000, 9, 4), (1, 1, 64, 500, 20, 1)], ids=lambda c: "I%d_C%d_B%d_Lh%d_T%d_tmax%d" % c)
+def test_host_io_mode_matches_copy_mode(case):
+    """IRB_FDL_HOST_IO: kernels read blocks and IR partitions from, and write output blocks to, mapped pinned host memory
+    (what the real-time adapter uses: no copy round trips).  Same samples as the copying mode, bit for bit; the
+    rolling partition refresh (irb_fdl_set_ir_partition) included."""
+    I, C, B, Lh, T, tmax = case
+    P = -(-Lh // B)
+    x = _streams(I, C, T * B, 9900)
+    h = decaying_ir(9950, P * B)
+    outs = []
+    for flags in (_lib.HOST_IO, 0):
+        with FdlEngine(I, C, B, P * B, max_blocks_per_call=tmax, flags=flags) as eng:
+            ys = []
+            for j in range(T):
+                for i in range(I):
+                    eng.set_ir_partition(i, j % P, h[(j % P) * B:(j % P + 1) * B])      # one partition per block, like the plug-in
+                ys.append(eng.process(x[:, j * B:(j + 1) * B]))
+            outs.append(np.concatenate(ys, axis=1))
+            if tmax > 1:
+                eng.reset()
+                outs[-1] = np.concatenate([outs[-1], eng.process(x[:, :tmax * B])], axis=1)   # a multi-block call too
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0
