@@ -110,7 +110,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             # not a fallback: the only implementation is the HIP library, so build it from source
             import subprocess
-            r = subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+            r = subprocess.run(["make", "-s", "-j3", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
             if r.returncode != 0 or not os.path.exists(SO_PATH):
                 raise ImportError(f"{SO_PATH} is missing and `make -C irbaboon_amd/csrc` failed "
                                   f"(there is no CPU fallback):\n{r.stderr[-2000:]}")

@@ -19,7 +19,7 @@ def _native_up_to_date():
     stale libirbfdl.so.  hipcc cross-compiles gfx950 without a GPU; on the GPU box the in-tree .so travels."""
     import subprocess
     for d in (os.path.join(ROOT, "irbaboon_amd", "csrc"), os.path.join(ROOT, "oracle")):
-        subprocess.run(["make", "-s", "-C", d], check=True)
+        subprocess.run(["make", "-s", "-j3", "-C", d], check=True)
 
 
 @pytest.fixture(scope="session")
