@@ -165,7 +165,6 @@ void choose_path(irb_fdl *h)
     // (measured, profiles/r02_handoff_ab.txt: granules win on narrow slices -- 1 to 8 streams: 5.41 -> 5.15, 7.29 -> 6.39,
     // 7.18 -> 6.65 us -- and lose from 32 streams on, where one reducer per stream sweeps 2048+ granules)
     h->cols_handoff = env_int("IRB_COLS_HANDOFF", (base * PS <= 256 && W < 64) ? 2 : 0);
-    if (env_int("IRB_COLS_SC1", 1) == 0) h->cols_handoff = 1;                 // older spelling of the fenced form
     if (h->cols_handoff < 0 || h->cols_handoff > 2) h->cols_handoff = 0;
 }
 

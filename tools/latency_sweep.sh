@@ -11,7 +11,9 @@ for ARGS in "1 1 256 96000 3000" "1 2 128 480000 3000" "1 2 256 2048 3000" "8 1 
   run IRB_COLS=0
   run IRB_COLS=1
   for w in 4 16 64; do for ps in 1 2 4 8 16; do run IRB_COLW=$w IRB_PSPLITS=$ps IRB_FUSED_ROWS=0; done; done
-  run IRB_COLS_SC1=0 IRB_FUSED_ROWS=0
+  run IRB_COLS_HANDOFF=0 IRB_FUSED_ROWS=0
+  run IRB_COLS_HANDOFF=1 IRB_FUSED_ROWS=0
+  run IRB_COLS_HANDOFF=2 IRB_FUSED_ROWS=0
 done
 out=gpurun_out/batch_sweep.txt
 : > $out
