@@ -284,6 +284,9 @@ def config5(dev, np):
         "deconvolve_no_smoothing_ms": round(t_raw, 3), "deconvolve_default_3x_smoothing_ms": round(t_smooth, 3),
         "invert_filter_ms": round(t_inv, 3), "samples": N,
         "Msamples_per_s_default": round(N / t_smooth / 1e3, 1),
+        "effective_GBps_end_to_end_no_smoothing": round(3 * 4.0 * N / t_raw / 1e6, 1),     # 2 signals in + 1 out over PCIe, fp32
+        "device_time": "per-kernel durations of this chain: profiles/r02_lfft_kernel_stats.csv (FFT passes 5-10 us each); the default "
+                       "chain's time is 3 x (2 MB D2H + ~1.5 ms sequential float running sum on the host + 2 MB H2D)",
         "note": "irb_deconvolve / irb_invert_filter one-shot calls on a 2^20-sample sweep capture (786432-sample sweep + silence, "
                 "4096-tap IR), wall clock from pageable host buffers incl. PCIe; fp/convolution.cpp:351-403, fp/ir.cpp:13-18"}
     ib.lib().irb_release_cached_plans()
