@@ -57,7 +57,6 @@ struct irb_fdl {
     bool nt = false;                         // non-temporal row loads in the fused kernel
     int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
                                              // `splits` then counts partition splits (workgroups per stream = CS * splits)
-    bool fused_deep = false;                 // fused kernel with 8 partitions per stripe in flight (one workgroup per CU)
     int cols_handoff = 0;                    // its hand-off (k_step_cols HO): 0 write-through slices + ticket, 1 fences + ticket, 2 tagged granules
     unsigned long long *d_gran = nullptr;    // [S][splits][N] granules of hand-off form 2
     unsigned *h_status = nullptr, *d_status = nullptr;   // host-mapped word a kernel raises when a bounded spin gives up
@@ -231,7 +230,6 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
             else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         }
         else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        else if (h->fused_deep) { FOR_N(h->N, irb::k_step_fused<NN, 8, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
         FOR_N(h->N, irb::k_step_split<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets));
@@ -345,7 +343,6 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
     if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
     h->tiled1 = h->nt;
-    h->fused_deep = env_int("IRB_FUSED_DEEP", 0) != 0;
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
     if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
 
