@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libirbfdl.so")
+SO_PATH = os.environ.get("IRB_LIB") or os.path.join(_HERE, "libirbfdl.so")     # IRB_LIB: another build of the same library (A/B measurements)
 
 IRB_OK, IRB_ERR_ARG, IRB_ERR_HIP, IRB_ERR_LAYOUT, IRB_ERR_STATE = 0, -1, -2, -3, -4
 FORCE_FUSED, FORCE_SPLIT, SPLIT_3LAUNCH, NO_PAIRING, FORCE_COLS, HOST_IO = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20

@@ -19,6 +19,10 @@
 
 #include "fft_wave.hpp"
 
+#ifndef IRB_TILED_SCHED_BARRIER
+#define IRB_TILED_SCHED_BARRIER 1
+#endif
+
 namespace irb {
 
 constexpr int kThreads = 256;
@@ -1106,6 +1110,9 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
                     h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
                     xr[TT - 1 - u] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - u, a.R) * G::L + col);
                 }
+                // keep the 16 loads together in front of the products: left alone, hipcc sinks every load to its first use
+                // and waits for it there (16 exposed L2 latencies per step instead of one)
+                if (IRB_TILED_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < TT; u++) {
                     const float p = packed ? 0.0f : h[u].y;
@@ -1167,6 +1174,7 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
                     h[u] = H2[(size_t) (k0 + u) * M + col];
                     xr[7 - u] = X2[(size_t) ring_slot(a.head, j0 - k0 - u, a.R) * M + col];
                 }
+                if (IRB_TILED_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // as in k_cmac_tiled: loads stay in front
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const float p = packed ? 0.0f : h[u].y;
