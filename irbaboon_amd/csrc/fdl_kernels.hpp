@@ -1199,22 +1199,31 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
 template <int N>
 __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, int nq, float2 *buf, int lane)
 {
-    constexpr int M = N / 2, L = M / 2;
+    constexpr int M = N / 2, L = M / 2, CPL = L >= kWave ? L / kWave : 1;
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    for (int c = lane; c < L; c += kWave) {
-        float4 v = src4[c];
-        int q = 1;
-        for (; q + 3 < nq; q += 4) {      // four independent loads in flight
-            const float4 w0 = src4[(size_t) q * L + c], w1 = src4[(size_t) (q + 1) * L + c];
-            const float4 w2 = src4[(size_t) (q + 2) * L + c], w3 = src4[(size_t) (q + 3) * L + c];
-            v.x += (w0.x + w1.x) + (w2.x + w3.x); v.y += (w0.y + w1.y) + (w2.y + w3.y);
-            v.z += (w0.z + w1.z) + (w2.z + w3.z); v.w += (w0.w + w1.w) + (w2.w + w3.w);
-        }
-        for (; q < nq; q++) {
-            const float4 w = src4[(size_t) q * L + c];
-            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
-        reinterpret_cast<float4 *>(buf)[c] = v;
+    float4 v[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four rows x all of this lane's columns per round, every load of the round issued before the first add (clamped
+    // rows / columns instead of predicated loads; a `load; add` loop waits for each load in turn)
+    for (int q0 = 0; q0 < nq; q0 += 4) {
+        float4 w[4][CPL];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                w[i][c] = src4[(size_t) min(q0 + i, nq - 1) * L + min(lane + c * kWave, L - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (q0 + i < nq) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) { v[c].x += w[i][c].x; v[c].y += w[i][c].y; v[c].z += w[i][c].z; v[c].w += w[i][c].w; }
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int col = lane + c * kWave;
+        if (L >= kWave || col < L) reinterpret_cast<float4 *>(buf)[col] = v[c];
     }
     wave_sync();
 }
