@@ -135,7 +135,10 @@ void  irb_host_free(void *p);
  * d_in + s*stride + j*block (floats); likewise d_out.  Asynchronous.            */
 int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long stride, int n_blocks);
 
-/* Wait for everything enqueued on the handle's stream (no reference counterpart: the reference is synchronous). */
+/* Wait for everything enqueued on the handle's stream (no reference counterpart: the reference is synchronous).
+ * Returns IRB_ERR_STATE if a step kernel's bounded in-kernel wait gave up since the last check (multi-workgroup steps
+ * of few streams hand partial spectra over inside one launch; a wait is abandoned after 50 ms instead of hanging the
+ * GPU, and the blocks of that step are then invalid).  The blocking process calls report the same condition. */
 int  irb_fdl_synchronize(irb_fdl *h);
 
 /* Stream-ordered timing on the handle's stream (hipEvent): `mark` records event
