@@ -1064,8 +1064,11 @@ __device__ __forceinline__ void cmac2(float4 &acc, const float4 x, const float4 
     acc.w = fmaf(x.z, h.w, acc.w);  acc.w = fmaf(x.w, h.z, acc.w);
 }
 
+#ifndef IRB_TILED_MIN_WAVES
+#define IRB_TILED_MIN_WAVES 4      // <= 128 VGPRs (2 spilled): 4 waves per SIMD instead of 3, +4..5 % on cache-resident calls
+#endif
 template <int N, int TT, bool NT = false>
-__global__ __launch_bounds__(kThreads) void k_cmac_tiled(StepArgs a)
+__global__ __launch_bounds__(kThreads, IRB_TILED_MIN_WAVES) void k_cmac_tiled(StepArgs a)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2;
