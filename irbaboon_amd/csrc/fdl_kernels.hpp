@@ -463,8 +463,10 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft(StepArgs a,
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int s = blockIdx.x * NF + wave;
-    stage_twiddles<N>(a.tw, l_tw);
+    TwiddleStage<N, kWave * NF> tws;
+    tws.load(a.tw);
     if (s < S) wave_load_block<M>(a.in + (size_t) s * a.in_stride, a.B, l_buf[wave], lane);
+    tws.store(l_tw);
     __syncthreads();
     if (s >= S) return;
     wave_fft<M, false>(l_buf[wave], l_tw, lane);
@@ -1035,8 +1037,10 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     const int item = blockIdx.x * NF + wave;
     const bool live = item < S * a.T;
     const int j = item % a.T, s = item / a.T;
-    stage_twiddles<N>(a.tw, l_tw);
+    TwiddleStage<N, kWave * NF> tws;
+    tws.load(a.tw);
     if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
+    tws.store(l_tw);
     __syncthreads();
     if (!live) return;
     wave_fft<M, false>(l_buf[wave], l_tw, lane);
@@ -1299,8 +1303,10 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *
     const int item = blockIdx.x * NF + wave;
     const bool live = item < nparts * nrows;
     const int k = item % nparts, r = item / nparts;
-    stage_twiddles<N>(tw, l_tw);
+    TwiddleStage<N, kWave * NF> tws;
+    tws.load(tw);
     if (live) wave_load_block<M>(ir + ((size_t) r * nparts + k) * B, B, l_buf[wave], lane);
+    tws.store(l_tw);
     __syncthreads();
     if (!live) return;
     wave_fft<M, false>(l_buf[wave], l_tw, lane);

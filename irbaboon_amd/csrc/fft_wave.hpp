@@ -53,6 +53,27 @@ __device__ __forceinline__ void stage_twiddles(const float2 *__restrict__ g_tw, 
     for (int i = threadIdx.x; i < N / 2; i += blockDim.x) put_twiddle<N>(l_tw, i, g_tw[i]);
 }
 
+// the same in two halves for a workgroup of NTHREADS threads, so that a kernel can issue its other global loads between
+// them: load() only issues the table loads, store() writes LDS (the first instruction that waits for them)
+template <int N, int NTHREADS>
+struct TwiddleStage {
+    static constexpr int PER = (N / 2 + NTHREADS - 1) / NTHREADS;
+    float2 r[PER];
+    __device__ __forceinline__ void load(const float2 *__restrict__ g_tw)
+    {
+#pragma unroll
+        for (int i = 0; i < PER; i++) r[i] = g_tw[min((int) threadIdx.x + i * NTHREADS, N / 2 - 1)];
+    }
+    __device__ __forceinline__ void store(float2 *l_tw) const
+    {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int idx = threadIdx.x + i * NTHREADS;
+            if (idx < N / 2) put_twiddle<N>(l_tw, idx, r[i]);
+        }
+    }
+};
+
 template <int N>
 __device__ __forceinline__ float2 twiddle(const float2 *l_tw, int i)   // W_N^i, 0 <= i < N
 {
