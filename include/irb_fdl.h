@@ -48,6 +48,9 @@ extern "C" {
 #define IRB_FDL_FORCE_COLS    0x10u /* always the column-sliced single-launch step (k_step_cols)   */
 #define IRB_FDL_HOST_IO       0x20u /* irb_fdl_process / set_ir_partition: kernels read and write mapped pinned host memory directly
                                        (zero copy; for small real-time engines: one launch + one wait per block, no copy round trips) */
+#define IRB_FDL_STEPWISE      0x40u /* a call of n <= max_blocks_per_call blocks runs n one-block steps, never the time-tiled
+                                       kernels; the FDL ring then holds exactly P slots (the real-time adapter's engine)   */
+#define IRB_FDL_NO_RT_KERNEL  0x80u /* irb_fdl_process_refresh: always the refresh launch + step launch per block (A/B, tests) */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */
@@ -120,6 +123,22 @@ int  irb_fdl_reset(irb_fdl *h);
  * in/out: host pointers, planar, one per stream (stream = instance*channels+ch),
  * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.     */
 int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
+
+/* Replaces: the body of the IRCAP_IDLE branch for the n_blocks complete blocks of one host callback
+ * (Source/PluginProcessor.cpp:452-518), in ONE wait: before block j is stepped, partition (first_partition + j) mod P
+ * of `instance` is re-derived from ir + that partition's offset (the rolling refresh, :455-461; IR channel 0 feeds every
+ * audio channel, :485), then the block goes through the FDL step (:463-510).  `ir`: host pointer to P*block samples.
+ * in/out as irb_fdl_process, n_blocks <= max_blocks_per_call; the handle must be IRB_FDL_STEPWISE (or one block per
+ * call).  A single stereo instance created with IRB_FDL_HOST_IO and a short IR ring (the plug-in adapter's engine) runs
+ * the whole call as one kernel launch and waits on a host-mapped completion word; other shapes enqueue a refresh launch
+ * and a step launch per block and wait once.  Blocks until done.                                                    */
+int  irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, float *const *out, int n_blocks,
+                             const float *ir, int first_partition);
+
+/* What this handle has asked of the HIP runtime since create: kernel launches, blocking waits, copy commands.
+ * Measurement support (bench.py reports launches and waits per real-time callback); no reference counterpart.   */
+int  irb_fdl_get_counters(const irb_fdl *h, unsigned long long *launches, unsigned long long *waits,
+                          unsigned long long *copies);
 
 /* Same steps (fp/convolution.cpp:128-213; RT Source/PluginProcessor.cpp:428-510) with one packed host buffer per
  * direction: stream s, block j at in + s*stride + j*block (floats).
@@ -205,6 +224,13 @@ int  irb_rt_process_block(irb_rt *p, float *const *buffer, int n);
 /* Replaces processBlockBypassed (Source/PluginProcessor.cpp:584-590): host-only ring that keeps the plug-in's
  * block delay while bypassed.  n must equal the prepared samples_per_block.            */
 int  irb_rt_process_block_bypassed(irb_rt *p, float *const *buffer, int n);
+/* Measurement support for bench.py (no reference counterpart: the reference has no timing code): runs n_callbacks
+ * irb_rt_process_block calls of n samples per channel on white noise and writes each callback's wall time in
+ * microseconds to us_out[n_callbacks]; irb_rt_counters reports callbacks made and what they asked of the HIP
+ * runtime (kernel launches, blocking waits, copy commands) since prepare_to_play.                               */
+int  irb_rt_time_callbacks(irb_rt *p, int n, int n_callbacks, float *us_out);
+int  irb_rt_counters(const irb_rt *p, unsigned long long *callbacks, unsigned long long *launches,
+                     unsigned long long *waits, unsigned long long *copies);
 int  irb_rt_latency(const irb_rt *p);
 int  irb_rt_partitions(const irb_rt *p);
 

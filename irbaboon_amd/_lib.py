@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IRB_LIB") or os.path.join(_HERE, "libirbfdl.so")     # IRB_LIB: another build of the same library (A/B measurements)
 
 IRB_OK, IRB_ERR_ARG, IRB_ERR_HIP, IRB_ERR_LAYOUT, IRB_ERR_STATE = 0, -1, -2, -3, -4
-FORCE_FUSED, FORCE_SPLIT, SPLIT_3LAUNCH, NO_PAIRING, FORCE_COLS, HOST_IO = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FORCE_FUSED, FORCE_SPLIT, SPLIT_3LAUNCH, NO_PAIRING, FORCE_COLS, HOST_IO, STEPWISE, NO_RT_KERNEL = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
 
 fpp = C.POINTER(C.POINTER(C.c_float))
 fp = C.POINTER(C.c_float)
@@ -46,6 +46,8 @@ SYMBOLS = [
     ("irb_fdl_set_ir_spectra", C.c_int, [C.c_void_p, C.c_int, fpp, C.c_int, C.c_int]),
     ("irb_fdl_reset", C.c_int, [C.c_void_p]),
     ("irb_fdl_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
+    ("irb_fdl_process_refresh", C.c_int, [C.c_void_p, C.c_int, fpp, fpp, C.c_int, fp, C.c_int]),
+    ("irb_fdl_get_counters", C.c_int, [C.c_void_p] + [C.POINTER(C.c_ulonglong)] * 3),
     ("irb_fdl_process_packed", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]),
     ("irb_host_alloc", C.c_void_p, [C.c_size_t]),
     ("irb_host_free", None, [C.c_void_p]),
@@ -70,6 +72,8 @@ SYMBOLS = [
     ("irb_rt_set_ir", C.c_int, [C.c_void_p, fp, C.c_int]),
     ("irb_rt_process_block", C.c_int, [C.c_void_p, fpp, C.c_int]),
     ("irb_rt_process_block_bypassed", C.c_int, [C.c_void_p, fpp, C.c_int]),
+    ("irb_rt_time_callbacks", C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    ("irb_rt_counters", C.c_int, [C.c_void_p] + [C.POINTER(C.c_ulonglong)] * 4),
     ("irb_rt_latency", C.c_int, [C.c_void_p]),
     ("irb_rt_partitions", C.c_int, [C.c_void_p]),
     # include/irb_deconv.h

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <vector>
 
@@ -53,6 +54,9 @@ struct irb_fdl {
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
     int tiled_splits_override = 0;           // tuning: IRB_TILED_SPLITS, read once at create
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
+    int tiled_kernel = 1;                    // time-tiled MAC: 0 k_cmac_tiled<N,8> (round 2), 1..3 k_cmac_tiled_pk variants (IRB_TILED_KERNEL)
+    int tileTT = 16;                         // outputs per time tile of that kernel
+    int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
     int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
@@ -60,6 +64,10 @@ struct irb_fdl {
     int cols_handoff = 0;                    // its hand-off (k_step_cols HO): 0 write-through slices + ticket, 1 fences + ticket, 2 tagged granules
     unsigned long long *d_gran = nullptr;    // [S][splits][N] granules of hand-off form 2
     unsigned *h_status = nullptr, *d_status = nullptr;   // host-mapped word a kernel raises when a bounded spin gives up
+    unsigned *h_done = nullptr, *d_done = nullptr;       // host-mapped completion word of the one-launch real-time callback (k_rt_pair)
+    unsigned done_seq = 0;
+    bool stepwise = false;                   // IRB_FDL_STEPWISE: a call of n blocks = n one-block steps, ring of P slots
+    unsigned long long n_launches = 0, n_waits = 0, n_copies = 0;   // what the host asked of the runtime since create (irb_fdl_get_counters)
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
     unsigned flags = 0;
@@ -82,6 +90,12 @@ struct irb_fdl {
 
 namespace {
 
+// every wait on / copy through the runtime is counted (irb_fdl_get_counters: launches, waits and copies per callback are
+// part of what bench.py reports for the real-time path)
+inline hipError_t irb_sync(irb_fdl *h) { h->n_waits++; return hipStreamSynchronize(h->stream); }
+#define COPY_ASYNC(h_, ...)   ((h_)->n_copies++, hipMemcpyAsync(__VA_ARGS__))
+#define COPY2D_ASYNC(h_, ...) ((h_)->n_copies++, hipMemcpy2DAsync(__VA_ARGS__))
+
 template <typename T>
 int dev_alloc(irb_fdl *h, T **p, size_t n)
 {
@@ -100,6 +114,18 @@ int dev_alloc(irb_fdl *h, T **p, size_t n)
     case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break;                   \
     case 2048: { constexpr int NN = 2048; __VA_ARGS__; } break;                   \
     case 4096: { constexpr int NN = 4096; __VA_ARGS__; } break;                   \
+    default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
+    }
+
+// the instantiations of the one-launch real-time callback (B <= 512: its LDS image fits the static 64 KiB)
+#define FOR_N_RT(N_, ...)                                                  \
+    switch (N_) {                                                          \
+    case 32:   { constexpr int NN = 32;   __VA_ARGS__; } break;                   \
+    case 64:   { constexpr int NN = 64;   __VA_ARGS__; } break;                   \
+    case 128:  { constexpr int NN = 128;  __VA_ARGS__; } break;                   \
+    case 256:  { constexpr int NN = 256;  __VA_ARGS__; } break;                   \
+    case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break;                   \
+    case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break;                   \
     default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
     }
 
@@ -174,10 +200,10 @@ constexpr int kTT = 8;                        // outputs per time tile (k_cmac_t
 int tiled_splits(const irb_fdl *h, int T)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
-    const int ntiles = (T + kTT - 1) / kTT;
+    const int ntiles = (T + h->tileTT - 1) / h->tileTT;
     const int by_work = std::max(1, (h->Ppad / kTT) / (stripes * 2));
     const long wgs = (long) h->S * ntiles;
-    const int by_chip = (int) std::max<long>(1, (768 + wgs - 1) / wgs);
+    const int by_chip = (int) std::max<long>(1, (h->tiled_chip_wgs + wgs - 1) / wgs);
     if (h->tiled_splits_override > 0) return std::max(1, std::min(by_work, h->tiled_splits_override));   // IRB_TILED_SPLITS
     return std::max(1, std::min(by_work, by_chip));
 }
@@ -187,6 +213,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     irb::StepArgs a;
     a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
+    a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -202,6 +229,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
 
 int launch_cols(irb_fdl *h, const irb::StepArgs &a)
 {
+    h->n_launches++;
     if (h->cols_handoff == 2) { LAUNCH_COLS_W(2) }
     else if (h->cols_handoff == 1) { LAUNCH_COLS_W(1) }
     else { LAUNCH_COLS_W(0) }
@@ -214,6 +242,7 @@ int check_status(irb_fdl *h)
 {
     if (h->h_status && *h->h_status) {
         *h->h_status = 0;
+        *h->h_done = 0;
         return fail(IRB_ERR_STATE, "in-kernel hand-off timed out (a producer workgroup never published its slice)");
     }
     return IRB_OK;
@@ -222,6 +251,7 @@ int check_status(irb_fdl *h)
 int launch_step(irb_fdl *h, const irb::StepArgs &a)
 {
     if (h->colW > 0) return launch_cols(h, a);
+    h->n_launches += (h->splits > 1 && (h->flags & IRB_FDL_SPLIT_3LAUNCH)) ? 3 : 1;
     if (h->splits <= 1) {
         // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
         // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
@@ -256,13 +286,24 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
     if (one_bin) a.nq = a.splits * stripes1;
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
-    const int ntiles = one_bin ? (T + 15) / 16 : (T + kTT - 1) / kTT;
+    const int ntiles = one_bin ? (T + 15) / 16 : (T + h->tileTT - 1) / h->tileTT;
+    const dim3 mac_grid(h->S * ntiles * a.splits), mac_block(irb::kThreads);
+    h->n_launches += 3;
     FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
-    if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
-    else if (h->nt && ntiles == 1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-    else { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<dim3(h->S * ntiles * a.splits), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-    FOR_N(h->N, irb::k_ifft_ola_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
+    const bool nt1 = h->nt && ntiles == 1;
+    if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (h->tiled_kernel == 0) {
+        if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+        else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    }
+    else if (h->tiled_kernel == 2) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 4, 2><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (h->tiled_kernel == 3) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 12, 4, 3><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (h->tiled_kernel == 4) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 8, 4><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else          { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((T + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
+                                                                 dim3(irb::kWave * (irb::OlaGeom<NN>::NB + 1)), 0, h->stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
     h->ovl_cur ^= 1;
     return IRB_OK;
@@ -270,6 +311,7 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
 
 int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int first_set, int first_partition)
 {
+    h->n_launches++;
     FOR_N(h->N, irb::k_ir_fft<NN><<<dim3((nparts * nrows + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF),
                                      dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(
                     d_ir, h->d_H, h->d_tw, h->B, h->Ppad, first_set, first_partition, nparts, nrows));
@@ -281,9 +323,9 @@ int upload_maps(irb_fdl *h)
 {
     h->pair = (h->C == 2) && !(h->flags & IRB_FDL_NO_PAIRING);
     for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
-    HIP_TRY(hipStreamSynchronize(h->stream));          // the pinned staging may still feed an earlier upload
+    HIP_TRY(irb_sync(h));          // the pinned staging may still feed an earlier upload
     for (int s = 0; s < h->S; s++) h->h_info[s] = make_int2(h->h_set_of_stream[s], h->h_np_of_set[h->h_set_of_stream[s]]);
-    HIP_TRY(hipMemcpyAsync(h->d_stream_info, h->h_info, sizeof(int2) * h->S, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(COPY_ASYNC(h, h->d_stream_info, h->h_info, sizeof(int2) * h->S, hipMemcpyHostToDevice, h->stream));
     return IRB_OK;
 }
 
@@ -301,11 +343,12 @@ void irb_fdl_destroy(irb_fdl *h)
 {
     if (!h) return;
     (void) hipSetDevice(h->device);
-    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    if (h->stream) (void) irb_sync(h);
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
     if (h->h_status) (void) hipHostFree(h->h_status);
+    if (h->h_done) (void) hipHostFree(h->h_done);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
@@ -336,8 +379,9 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->P = (cfg->max_ir_len + h->B - 1) / h->B;
     h->Ppad = (h->P + kTT - 1) / kTT * kTT;
     h->Tmax = cfg->max_blocks_per_call;
-    h->R = h->Tmax > 1 ? h->Ppad + h->Tmax + kTT : h->P;     // tiled path: P past blocks + the call's blocks + tile overhang
     h->flags = cfg->flags;
+    h->stepwise = (h->flags & IRB_FDL_STEPWISE) != 0 || h->Tmax == 1;
+    h->R = h->stepwise ? h->P : h->Ppad + h->Tmax + kTT;     // tiled path: P past blocks + the call's blocks + tile overhang
     choose_path(h);
     h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
     if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
@@ -345,6 +389,10 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->tiled1 = h->nt;
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
     if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
+    h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
+    if (h->tiled_kernel < 0 || h->tiled_kernel > 4) h->tiled_kernel = 1;
+    h->tileTT = (h->tiled_kernel == 0 || h->tiled_kernel == 4) ? kTT : h->tiled_kernel == 3 ? 12 : 16;
+    h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", 768));
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };
@@ -364,7 +412,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         {
             const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
             size_t rows = (size_t) h->S * std::max(h->splits, 1);
-            for (int T = 2; T <= h->Tmax; T++) rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
+            for (int T = 2; T <= h->Tmax && !h->stepwise; T++) rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
             h->part_rows = rows;
         }
         if (!guard(dev_alloc(h, &h->d_part, h->part_rows * h->M))) break;
@@ -386,11 +434,14 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_np_of_set), sizeof(int) * h->S)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info), sizeof(int2) * h->S)) != hipSuccess ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_status), sizeof(unsigned), hipHostMallocMapped)) != hipSuccess ||
-            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_status), h->h_status, 0)) != hipSuccess) {
+            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_status), h->h_status, 0)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_done), 64, hipHostMallocMapped)) != hipSuccess ||
+            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_done), h->h_done, 0)) != hipSuccess) {
             rc = fail(IRB_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
             break;
         }
         *h->h_status = 0;
+        *h->h_done = 0;
         // twiddles: W_N^j in double, rounded to float
         std::vector<float2> tw(h->N);
         for (int j = 0; j < h->N; j++) {
@@ -410,7 +461,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         }
         for (int s = 0; s < h->S; s++) { h->h_set_of_stream[s] = s; h->h_np_of_set[s] = 0; }   // no IR yet: output is silence
         if (!guard(upload_maps(h))) break;
-        if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { rc = fail(IRB_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
+        if ((e = irb_sync(h)) != hipSuccess) { rc = fail(IRB_ERR_HIP, "sync: %s", hipGetErrorString(e)); break; }
     } while (0);
     if (rc != IRB_OK) { char keep[sizeof g_err]; std::memcpy(keep, g_err, sizeof keep); irb_fdl_destroy(h); std::memcpy(g_err, keep, sizeof keep); return rc; }
     *out = h;
@@ -437,7 +488,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
         return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
     for (int c = 0; c < ir_channels; c++) if (!ir[c] && len > 0) return fail(IRB_ERR_ARG, "ir[%d] is null", c);
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));       // the pinned IR staging may still feed an earlier partition refresh
+    HIP_TRY(irb_sync(h));       // the pinned IR staging may still feed an earlier partition refresh
     const int np = (len + h->B - 1) / h->B;
     const int nrows = (ir_channels == 2 && h->C == 2) ? 2 : 1;        // fp/convolution.cpp:94-101
     const size_t row = (size_t) np * h->B;
@@ -452,7 +503,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
     }
     const int first_set = instance * h->C;
     if (np > 0) {
-        HIP_TRY(hipMemcpyAsync(h->d_irtime, h->h_ir, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(COPY_ASYNC(h, h->d_irtime, h->h_ir, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
         int rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
         if (rc != IRB_OK) return rc;
     }
@@ -467,7 +518,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
     }
     int rc = upload_maps(h);
     if (rc != IRB_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(irb_sync(h));
     return IRB_OK;
 }
 
@@ -486,7 +537,7 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
     if (h->host_io) {
         rc = launch_ir_fft(h, h->d_hir + (size_t) partition * h->B, 1, 1, first_set, partition);     // the kernel reads the pinned staging itself
     } else {
-        HIP_TRY(hipMemcpyAsync(ds, hs, sizeof(float) * h->B, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(COPY_ASYNC(h, ds, hs, sizeof(float) * h->B, hipMemcpyHostToDevice, h->stream));
         rc = launch_ir_fft(h, ds, 1, 1, first_set, partition);
     }
     if (rc != IRB_OK) return rc;
@@ -508,9 +559,9 @@ int irb_fdl_get_ir_spectra(irb_fdl *h, int instance, int channel, float *spectra
     if (n_partitions < 0 || n_partitions > h->h_np_of_set[set])
         return fail(IRB_ERR_ARG, "n_partitions %d exceeds the %d partitions held", n_partitions, h->h_np_of_set[set]);
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(spectra, h->d_H + (size_t) set * h->Ppad * h->M, sizeof(float2) * (size_t) n_partitions * h->M,
+    HIP_TRY(COPY_ASYNC(h, spectra, h->d_H + (size_t) set * h->Ppad * h->M, sizeof(float2) * (size_t) n_partitions * h->M,
                            hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(irb_sync(h));
     return IRB_OK;
 }
 
@@ -526,7 +577,7 @@ int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra
     for (int r = 0; r < ir_channels; r++) {
         if (!spectra[r] && np > 0) return fail(IRB_ERR_ARG, "spectra[%d] is null", r);
         float2 *dst = h->d_H + (size_t) (first_set + r) * h->Ppad * h->M;
-        if (np > 0) HIP_TRY(hipMemcpyAsync(dst, spectra[r], sizeof(float2) * (size_t) np * h->M, hipMemcpyHostToDevice, h->stream));
+        if (np > 0) HIP_TRY(COPY_ASYNC(h, dst, spectra[r], sizeof(float2) * (size_t) np * h->M, hipMemcpyHostToDevice, h->stream));
         const int np_pad = std::min((np + kTT - 1) / kTT * kTT, h->Ppad);
         if (np_pad > np) HIP_TRY(hipMemsetAsync(dst + (size_t) np * h->M, 0, sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
     }
@@ -536,7 +587,7 @@ int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra
     }
     int rc = upload_maps(h);
     if (rc != IRB_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(irb_sync(h));
     return IRB_OK;
 }
 
@@ -560,7 +611,7 @@ int irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long str
     if (stride < (long) n_blocks * h->B && h->S > 1) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
     HIP_TRY(hipSetDevice(h->device));
     for (int j = 0; j < n_blocks;) {
-        const int T = std::min(n_blocks - j, h->Tmax);
+        const int T = h->stepwise ? 1 : std::min(n_blocks - j, h->Tmax);
         irb::StepArgs a = step_args(h, d_in + (size_t) j * h->B, d_out + (size_t) j * h->B, stride);
         int rc = (T > 1) ? launch_tiled(h, a, T) : launch_step(h, a);
         if (rc != IRB_OK) return rc;
@@ -574,7 +625,7 @@ int irb_fdl_synchronize(irb_fdl *h)
 {
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(irb_sync(h));
     return check_status(h);
 }
 
@@ -588,17 +639,17 @@ static int process_chunk_begin(irb_fdl *h, const float *const *in, int done, int
     for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
     if (h->host_io)                                   // zero copy: input half -> kernels -> output half, both in mapped host memory
         return irb_fdl_process_device(h, h->d_hio, h->d_hio + (size_t) h->S * stride, stride, nb);
-    HIP_TRY(hipMemcpyAsync(h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(COPY_ASYNC(h, h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
     int rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
     if (rc != IRB_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(COPY_ASYNC(h, h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
     return IRB_OK;
 }
 
 static int process_chunk_end(irb_fdl *h, float *const *out, int done, int nb)
 {
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));      // (polling hipStreamQuery instead was measured: no gain)
+    HIP_TRY(irb_sync(h));      // (polling hipStreamQuery instead was measured: no gain)
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) nb * h->B;
     const float *res = h->h_io + (h->host_io ? (size_t) h->S * stride : 0);
@@ -620,6 +671,106 @@ int irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n
     return IRB_OK;
 }
 
+// Wait for the completion word of a k_rt_pair launch: the audio thread spins on host memory (the kernel's last store
+// lands there ~1 us after its last output sample) instead of entering the runtime's wait.  Bounded: after 2 ms the
+// runtime's own wait takes over, which also surfaces a failed launch.
+static int wait_done_word(irb_fdl *h, unsigned seq)
+{
+    volatile unsigned *w = h->h_done;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; *w != seq; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) {
+                HIP_TRY(irb_sync(h));
+                if (*w != seq) return fail(IRB_ERR_STATE, "real-time step finished without its completion word");
+                break;
+            }
+        }
+    }
+    // let the runtime retire its finished commands now and then (nothing else on this path ever asks it to)
+    if ((seq & 255u) == 0) (void) hipStreamQuery(h->stream);
+    return IRB_OK;
+}
+
+int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, float *const *out, int n_blocks,
+                            const float *ir, int first_partition)
+{
+    if (!h || !in || !out || !ir) return fail(IRB_ERR_ARG, "null argument");
+    if (instance < 0 || instance >= h->I) return fail(IRB_ERR_ARG, "instance %d out of range", instance);
+    if (n_blocks < 0 || n_blocks > h->Tmax) return fail(IRB_ERR_ARG, "n_blocks %d outside [0, max_blocks_per_call = %d]", n_blocks, h->Tmax);
+    if (first_partition < 0 || first_partition >= h->P) return fail(IRB_ERR_ARG, "partition %d out of range [0,%d)", first_partition, h->P);
+    if (!h->stepwise) return fail(IRB_ERR_STATE, "irb_fdl_process_refresh needs IRB_FDL_STEPWISE (or max_blocks_per_call = 1)");
+    for (int s = 0; s < h->S; s++) if (!in[s] || !out[s]) return fail(IRB_ERR_ARG, "in/out[%d] is null", s);
+    if (n_blocks == 0) return IRB_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int first_set = instance * h->C;
+    bool changed = false;                                // Source/PluginProcessor.cpp:485: IR channel 0 for every channel, all P rows in use
+    for (int c = 0; c < h->C; c++) {
+        if (h->h_set_of_stream[first_set + c] != first_set || h->h_np_of_set[first_set + c] != h->P) changed = true;
+        h->h_set_of_stream[first_set + c] = first_set;
+        h->h_np_of_set[first_set + c] = h->P;
+    }
+    if (changed) { int rc = upload_maps(h); if (rc != IRB_OK) return rc; }
+
+    const long stride = (long) h->Tmax * h->B;
+    const size_t n = (size_t) n_blocks * h->B;
+    // one launch for the whole call: a single stereo instance whose step runs in one workgroup, blocks and IR samples
+    // in mapped host memory (what the plug-in adapter creates)
+    const bool one_launch = h->host_io && h->I == 1 && h->pair && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
+                            !(h->flags & IRB_FDL_NO_RT_KERNEL);
+    if (one_launch) {
+        for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s], sizeof(float) * n);
+        for (int j = 0; j < n_blocks; j++) {
+            const int p = (first_partition + j) % h->P;
+            std::memcpy(h->h_ir + (size_t) p * h->B, ir + (size_t) p * h->B, sizeof(float) * h->B);
+        }
+        irb::StepArgs a = step_args(h, h->d_hio, h->d_hio + (size_t) h->S * stride, stride);
+        a.T = n_blocks; a.rf_src = h->d_hir; a.rf_part = first_partition;
+        a.done = h->d_done; a.done_seq = ++h->done_seq;
+        if (a.done_seq == 0) a.done_seq = ++h->done_seq;            // 0 is the word's initial value
+        h->n_launches++;
+        FOR_N_RT(h->N, irb::k_rt_pair<NN><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a));
+        HIP_TRY(hipGetLastError());
+        h->t += n_blocks;
+        h->n_waits++;
+        int rc = wait_done_word(h, a.done_seq);
+        if (rc != IRB_OK) return rc;
+        const float *res = h->h_io + (size_t) h->S * stride;
+        for (int s = 0; s < h->S; s++) std::memcpy(out[s], res + (size_t) s * stride, sizeof(float) * n);
+        return IRB_OK;
+    }
+    // any other engine shape: refresh launch + step launch per block, all enqueued before the single wait
+    for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s], sizeof(float) * n);
+    const float *d_src = h->host_io ? h->d_hio : h->d_in;
+    float *d_dst = h->host_io ? h->d_hio + (size_t) h->S * stride : h->d_out;
+    if (!h->host_io) HIP_TRY(COPY_ASYNC(h, h->d_in, h->h_io, sizeof(float) * (size_t) h->S * stride, hipMemcpyHostToDevice, h->stream));
+    for (int j = 0; j < n_blocks; j++) {
+        const int p = (first_partition + j) % h->P;
+        int rc = irb_fdl_set_ir_partition(h, instance, p, ir + (size_t) p * h->B);
+        if (rc != IRB_OK) return rc;
+        rc = irb_fdl_process_device(h, d_src + (size_t) j * h->B, d_dst + (size_t) j * h->B, stride, 1);
+        if (rc != IRB_OK) return rc;
+    }
+    if (!h->host_io) HIP_TRY(COPY_ASYNC(h, h->h_io, h->d_out, sizeof(float) * (size_t) h->S * stride, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(irb_sync(h));
+    const float *res = h->h_io + (h->host_io ? (size_t) h->S * stride : 0);
+    for (int s = 0; s < h->S; s++) std::memcpy(out[s], res + (size_t) s * stride, sizeof(float) * n);
+    return check_status(h);
+}
+
+int irb_fdl_get_counters(const irb_fdl *h, unsigned long long *launches, unsigned long long *waits, unsigned long long *copies)
+{
+    if (!h) return fail(IRB_ERR_ARG, "null handle");
+    if (launches) *launches = h->n_launches;
+    if (waits) *waits = h->n_waits;
+    if (copies) *copies = h->n_copies;
+    return IRB_OK;
+}
+
 int irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride, int n_blocks)
 {
     if (!h || !in || !out) return fail(IRB_ERR_ARG, "null argument");
@@ -630,13 +781,13 @@ int irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride,
     for (int done = 0; done < n_blocks; done += h->Tmax) {
         const int nb = std::min(h->Tmax, n_blocks - done);
         const size_t width = sizeof(float) * (size_t) nb * h->B;
-        HIP_TRY(hipMemcpy2DAsync(h->d_in, sizeof(float) * dstride, in + (size_t) done * h->B, sizeof(float) * stride, width, h->S,
+        HIP_TRY(COPY2D_ASYNC(h, h->d_in, sizeof(float) * dstride, in + (size_t) done * h->B, sizeof(float) * stride, width, h->S,
                                  hipMemcpyHostToDevice, h->stream));
         int rc = irb_fdl_process_device(h, h->d_in, h->d_out, dstride, nb);
         if (rc != IRB_OK) return rc;
-        HIP_TRY(hipMemcpy2DAsync(out + (size_t) done * h->B, sizeof(float) * stride, h->d_out, sizeof(float) * dstride, width, h->S,
+        HIP_TRY(COPY2D_ASYNC(h, out + (size_t) done * h->B, sizeof(float) * stride, h->d_out, sizeof(float) * dstride, width, h->S,
                                  hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(irb_sync(h));
         rc = check_status(h);
         if (rc != IRB_OK) return rc;
     }
@@ -680,8 +831,8 @@ int irb_fdl_upload(irb_fdl *h, float *d_dst, const float *src, size_t n)
 {
     if (!h || !d_dst || !src) return fail(IRB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(d_dst, src, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(COPY_ASYNC(h, d_dst, src, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(irb_sync(h));
     return IRB_OK;
 }
 
@@ -689,8 +840,8 @@ int irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n)
 {
     if (!h || !dst || !d_src) return fail(IRB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpyAsync(dst, d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(COPY_ASYNC(h, dst, d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(irb_sync(h));
     return IRB_OK;
 }
 
@@ -749,15 +900,15 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             }
             hipError_t e = hipSuccess;
             for (int c = 0; c < audio_ch && e == hipSuccess; c++)       // only the blocks of this call, per channel
-                e = hipMemcpyAsync(h->d_in + (size_t) c * stride, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) n,
+                e = COPY_ASYNC(h, h->d_in + (size_t) c * stride, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) n,
                                    hipMemcpyHostToDevice, h->stream);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
             rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
             if (rc != IRB_OK) break;
             for (int c = 0; c < audio_ch && e == hipSuccess; c++)
-                e = hipMemcpyAsync(h->h_io + (size_t) c * stride, h->d_out + (size_t) c * stride, sizeof(float) * (size_t) n,
+                e = COPY_ASYNC(h, h->h_io + (size_t) c * stride, h->d_out + (size_t) c * stride, sizeof(float) * (size_t) n,
                                    hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = irb_sync(h);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
             const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;
             const long take = std::max<long>(0, std::min<long>(n, lim - s0));          // :225-227

@@ -59,6 +59,11 @@ struct StepArgs {
     // time-tiled path (several blocks per call)
     float        *ovl_next;     // overlap written by the last block of the call (double buffered)
     int           T, nq;        // blocks in this call; partial rows per output (splits * stripes)
+    // real-time callback in one launch (k_rt_pair): rolling IR-partition refresh + completion word
+    const float  *rf_src;       // time-domain IR [P*B] (host-mapped): block j re-derives partition (rf_part + j) mod P from it
+    int           rf_part;
+    unsigned     *done;         // host-mapped word that receives done_seq after the last output store (nullptr: none)
+    unsigned      done_seq;
 };
 
 #ifdef IRB_STAMPS
@@ -1315,3 +1320,6 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *
 }
 
 }  // namespace irb
+
+#include "fdl_tiled_pk.hpp"
+#include "fdl_rt_kernel.hpp"

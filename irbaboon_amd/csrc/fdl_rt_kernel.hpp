@@ -1,0 +1,144 @@
+// fdl_rt_kernel.hpp -- the real-time callback of the plug-in (reference Source/PluginProcessor.cpp:452-518) as ONE launch.
+// Included by fdl_kernels.hpp.
+//
+// k_rt_pair<N>: one workgroup per stereo instance whose two channels multiply with the same IR spectra (the plug-in
+// feeds IR channel 0 to both, :485).  For each of the call's T blocks, in order:
+//   * wave 2 re-derives ONE IR partition from the time-domain IR (the rolling refresh, :455-461): block j of the call
+//     refreshes partition (rf_part + j) mod P -- forward FFT next to the two audio FFTs of waves 0 and 1, spectrum into
+//     the H row for later launches and into LDS for this block;
+//   * all four waves multiply-accumulate the older partitions straight from HBM/L2, skipping the row being refreshed;
+//   * partition 0 pairs with the spectra the audio FFTs just produced, the refreshed partition with its LDS copy;
+//   * inverse FFTs, overlap-add (:504-510), outputs to (host-mapped) memory.
+// Blocks of one call are serialised by workgroup barriers (one workgroup owns the instance, so there is no hand-off
+// between workgroups), and the last thing the kernel does is a system-scope store of `done_seq` to a host-mapped word:
+// the audio thread spins on that word instead of entering the runtime's wait.  One launch and one wait per callback
+// whatever the host block size (round 2: two launches and one runtime wait per 256-sample block).
+#pragma once
+
+namespace irb {
+
+template <int N>
+struct LdsRt {
+    static constexpr int M = N / 2;
+    float2 tw[TwLds<N>::SIZE];
+    float2 buf[3][M];                                  // FFT work buffers: audio channel 0, channel 1, the IR partition
+    float2 hnew[M];                                    // packed spectrum of the partition refreshed with this block
+    float2 scratch[2][MacGeom<N>::STRIPES * M];        // new audio spectra, then the stripe partials
+};
+
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2, U = 4;
+    __shared__ LdsRt<N> lds;
+    const int s0 = 2 * blockIdx.x;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int2 si = a.stream_info[s0];
+    const int set = si.x, np = si.y;
+    float2 *Hs = const_cast<float2 *>(a.H) + (size_t) set * a.P * M;
+    const float4 *H4 = reinterpret_cast<const float4 *>(Hs);
+    float2 *Xs[2] = {a.X + (size_t) s0 * a.R * M, a.X + (size_t) (s0 + 1) * a.R * M};
+    const float4 *X4[2] = {reinterpret_cast<const float4 *>(Xs[0]), reinterpret_cast<const float4 *>(Xs[1])};
+    const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
+    const float4 *hnew4 = reinterpret_cast<const float4 *>(lds.hnew);
+
+    stage_twiddles<N>(a.tw, lds.tw);                   // once for every block of the call (first barrier below covers it)
+
+    for (int j = 0; j < a.T; j++) {
+        const int head = (a.head + j) % a.R;
+        const int rp = np > 0 ? (a.rf_part + j) % np : 0;
+        // small loads first: the new audio blocks + saved overlaps (waves 0, 1), the IR partition's samples (wave 2)
+        BlockIo<N> io;
+        if (wave < 2) io.load(a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) j * a.B, a.ovl + (size_t) (s0 + wave) * a.B, a.B, lane);
+        else if (wave == 2) io.load(a.rf_src + (size_t) rp * a.B, a.rf_src + (size_t) rp * a.B, a.B, lane);
+        // rows that meet operands still in flight: H row 0 (partition 0 pairs with this block's spectra) and the FDL rows
+        // the refreshed partition pairs with
+        int slot_r = head - rp;
+        if (slot_r < 0) slot_r += a.R;
+        float4 h0[G::CPT], xr0[G::CPT], xr1[G::CPT];
+#pragma unroll
+        for (int c = 0; c < G::CPT; c++) {
+            h0[c] = H4[col + c * G::LW];
+            xr0[c] = X4[0][(size_t) slot_r * G::L + col + c * G::LW];
+            xr1[c] = X4[1][(size_t) slot_r * G::L + col + c * G::LW];
+        }
+
+        // older partitions 1 .. np-1 except the one being refreshed (its H row is rewritten by wave 2 in this block)
+        float4 acc[2][G::CPT];
+        float2 dc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+        for (int c = 0; c < G::CPT; c++) { acc[0][c] = make_float4(0.f, 0.f, 0.f, 0.f); acc[1][c] = acc[0][c]; }
+        for (int k = 1 + stripe; k < np; k += U * G::STRIPES) {
+            float4 h[U][G::CPT], x0[U][G::CPT], x1[U][G::CPT];
+#pragma unroll
+            for (int u = 0; u < U; u++) {              // clamped, never predicated: all loads of the group in flight together
+                const int kk = min(k + u * G::STRIPES, np - 1);
+                int slot = head - kk;
+                if (slot < 0) slot += a.R;
+#pragma unroll
+                for (int c = 0; c < G::CPT; c++) {
+                    h[u][c] = H4[(size_t) kk * G::L + col + c * G::LW];
+                    x0[u][c] = X4[0][(size_t) slot * G::L + col + c * G::LW];
+                    x1[u][c] = X4[1][(size_t) slot * G::L + col + c * G::LW];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int kk = k + u * G::STRIPES;
+                const bool live = kk < np && kk != rp;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < G::CPT; c++) {
+                    cmac_pair(acc[0][c], dc[0], live ? x0[u][c] : z, h[u][c], c == 0);
+                    cmac_pair(acc[1][c], dc[1], live ? x1[u][c] : z, h[u][c], c == 0);
+                }
+            }
+        }
+
+        if (wave < 3) io.block_to_lds(lds.buf[wave], a.B, lane);
+        __syncthreads();
+        if (wave < 2) {                                // new audio blocks: FFT, spectrum to LDS (partition 0) and into the ring
+            wave_fft<M, false>(lds.buf[wave], lds.tw, lane);
+            float2 *ring = Xs[wave] + (size_t) head * M;
+            float2 *sc = lds.scratch[wave];
+            wave_split_forward<M>(lds.buf[wave], lds.tw, lane, [&](int b, float2 v) { sc[b] = v; ring[b] = v; });
+        } else if (wave == 2 && np > 0) {              // the refreshed IR partition: spectrum to LDS and into its H row
+            wave_fft<M, false>(lds.buf[2], lds.tw, lane);
+            float2 *row = Hs + (size_t) rp * M;
+            wave_split_forward<M>(lds.buf[2], lds.tw, lane, [&](int b, float2 v) { lds.hnew[b] = v; row[b] = v; });
+        }
+        __syncthreads();
+        if (np > 0 && threadIdx.x < G::LW) {
+#pragma unroll
+            for (int c = 0; c < G::CPT; c++) {
+                const float4 hn = hnew4[col + c * G::LW];
+                const float4 hp0 = rp == 0 ? hn : h0[c];
+                cmac_pair(acc[0][c], dc[0], reinterpret_cast<const float4 *>(lds.scratch[0])[col + c * G::LW], hp0, c == 0);
+                cmac_pair(acc[1][c], dc[1], reinterpret_cast<const float4 *>(lds.scratch[1])[col + c * G::LW], hp0, c == 0);
+                if (rp != 0) {
+                    cmac_pair(acc[0][c], dc[0], xr0[c], hn, c == 0);
+                    cmac_pair(acc[1][c], dc[1], xr1[c], hn, c == 0);
+                }
+            }
+        }
+        __syncthreads();
+        reduce_stripes<N>(acc[0], dc[0], lds.scratch[0], lds.buf[0]);
+        reduce_stripes<N>(acc[1], dc[1], lds.scratch[1], lds.buf[1]);
+        if (wave < 2) {
+            wave_split_inverse<M>(lds.buf[wave], lds.tw, lane);
+            wave_fft<M, true>(lds.buf[wave], lds.tw, lane);
+            io.overlap_add(lds.buf[wave], a.B, a.ovl + (size_t) (s0 + wave) * a.B,
+                           a.out + (size_t) (s0 + wave) * a.out_stride + (size_t) j * a.B, lane);
+        }
+        // end of the block: its ring slot, H row and overlap are complete (every wave has drained its stores) before
+        // the next block of this call reads them; one workgroup, one CU: a workgroup barrier is the whole hand-off
+        __syncthreads();
+    }
+    if (a.done != nullptr && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the output blocks reach host memory before the word
+        __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace irb

@@ -1,0 +1,214 @@
+// fdl_tiled_pk.hpp -- the time-tiled multiply-accumulate of calls that carry T > 1 blocks per stream, second
+// generation (round 3), and the inverse-FFT / overlap-add kernel that follows it.  Included by fdl_kernels.hpp.
+//
+// What round 2's k_cmac_tiled<N,8> was bound by (tools/valu_peak.hip + its own byte count): a lane multiplies
+// 8 partitions x 8 outputs x 2 bins per step = 512 v_fma_f32 from 16 row loads of 16 B, i.e. 4 flop per byte
+// through the CU's vector L1 (64 B/clk): at the fp32 vector peak the L1 would have to deliver exactly its own
+// peak, so the kernel sat where two equally loaded pipes without perfect overlap sit (0.36 of 157 TFLOP/s).
+// This kernel
+//   * multiplies with v_pk_fma_f32 (two FMAs per lane per instruction, operand halves picked by op_sel /
+//     neg_lo): one complex multiply-accumulate = 2 instructions instead of 4, and the measured packed rate
+//     needs half the resident waves (130 TFLOP/s at 2 waves per SIMD, 145 at 4; v_fma_f32: 115 / 125);
+//   * keeps a 16-output tile: per U partitions 2U row loads feed 16 U complex products per bin (8 flop per
+//     L1 byte), the X window lives in a register ring whose indices are compile-time constants (the loop is
+//     unrolled over the ring period), so the window never moves between registers.
+// The arithmetic per accumulator is the same FMA sequence as cmac2(): results are bit-identical to k_cmac_tiled.
+#pragma once
+
+namespace irb {
+
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+// acc += x * h for one complex bin, as two packed FMAs:
+//   acc.xy += ( x.x, x.x) * (f.x, f.y)
+//   acc.xy += (-x.y, x.y) * (g.y, g.x)
+// f == g == h for an ordinary bin; for packed bin 0 (DC and Nyquist: two real products) f = (h.x, 0), g = (h.y, 0).
+__device__ __forceinline__ void cmac_pk(v2f_t &acc, const v2f_t x, const v2f_t f, const v2f_t g)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(f));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(x), "v"(g));
+}
+
+template <int TT, int U>
+struct TilePk {
+    static constexpr int W = (TT + U - 1 + U - 1) / U * U;      // register ring: >= TT+U-1 rows, a multiple of U
+    static constexpr int PERIOD = W / U;                         // steps after which the ring indices repeat
+    // logical window row i (time j0 - k0 - (U-1) + i) of step S lives in ring register (i - S*U) mod W
+    static constexpr int phys(int i, int S) { return ((i - S * U) % W + W) % W; }
+};
+
+// one step of the tile: U partitions [k0, k0+U) against the TT outputs of the tile
+template <int N, int TT, int U, int S, bool NT, bool PACKED>
+__device__ __forceinline__ void tile_step(const float4 *__restrict__ H4, const float4 *__restrict__ X4, int col, int k0, int j0,
+                                          int head, int R, float4 (&xr)[TilePk<TT, U>::W], v2f_t (&acc)[TT][2], bool packed)
+{
+    using G = MacGeom<N>;
+    using TP = TilePk<TT, U>;
+    float4 h[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
+        xr[TP::phys(U - 1 - u, S)] = ld16<NT>(X4 + (size_t) ring_slot(head, j0 - k0 - u, R) * G::L + col);
+    }
+    __builtin_amdgcn_sched_barrier(0);         // loads first (see k_cmac_tiled)
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const v2f_t hz = {h[u].z, h[u].w};
+        v2f_t f = {h[u].x, h[u].y}, g = f;
+        if constexpr (PACKED) {                // only the wave that holds column 0 runs this variant
+            f = v2f_t{h[u].x, packed ? 0.0f : h[u].y};
+            g = v2f_t{packed ? h[u].y : h[u].x, packed ? 0.0f : h[u].y};
+        }
+#pragma unroll
+        for (int j = 0; j < TT; j++) {
+            const float4 x = xr[TP::phys(j - u + U - 1, S)];
+            cmac_pk(acc[j][0], v2f_t{x.x, x.y}, f, g);
+            cmac_pk(acc[j][1], v2f_t{x.z, x.w}, hz, hz);
+        }
+    }
+}
+
+// the PERIOD steps of one trip around the register ring, S = 0 .. PERIOD-1, in one basic block
+template <int N, int TT, int U, int S, bool NT, bool PACKED>
+__device__ __forceinline__ void tile_period(const float4 *__restrict__ H4, const float4 *__restrict__ X4, int col, int k0, int j0,
+                                            int head, int R, float4 (&xr)[TilePk<TT, U>::W], v2f_t (&acc)[TT][2], bool packed)
+{
+    if constexpr (S < TilePk<TT, U>::PERIOD) {
+        tile_step<N, TT, U, S, NT, PACKED>(H4, X4, col, k0 + S * U, j0, head, R, xr, acc, packed);
+        tile_period<N, TT, U, S + 1, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
+    }
+}
+
+template <int N, int TT, int U, bool NT, bool PACKED>
+__device__ __forceinline__ void tile_run(const float4 *__restrict__ H4, const float4 *__restrict__ X4, int col, int sb, int se, int j0,
+                                         int head, int R, v2f_t (&acc)[TT][2], bool packed)
+{
+    using G = MacGeom<N>;
+    using TP = TilePk<TT, U>;
+    float4 xr[TP::W];
+    int k0 = sb;
+#pragma unroll
+    for (int i = U; i < TT + U - 1; i++)
+        xr[TP::phys(i, 0)] = ld16<NT>(X4 + (size_t) ring_slot(head, j0 - k0 - (U - 1) + i, R) * G::L + col);
+    // whole trips around the ring: every register index is a constant and nothing moves between registers
+#pragma unroll 1
+    for (; k0 + U * TP::PERIOD <= se; k0 += U * TP::PERIOD)
+        tile_period<N, TT, U, 0, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
+    // the last < PERIOD steps: step 0 again, the window moved down the ring by U registers after each
+#pragma unroll 1
+    for (; k0 < se; k0 += U) {
+        tile_step<N, TT, U, 0, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
+#pragma unroll
+        for (int i = TT + U - 2; i >= U; i--) xr[TP::phys(i, 0)] = xr[TP::phys(i - U, 0)];
+    }
+}
+
+// grid = S * ceil(T/TT) * splits, as k_cmac_tiled; partial spectra part[s][j][q][M], q = split * STRIPES + stripe.
+// H rows are zero padded to multiples of 8 by the host; U divides 8.
+template <int N, int TT, int U, int MINW, bool NT = false>
+__global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2;
+    static_assert(8 % U == 0, "U must divide the H row padding");
+    const int ntiles = (a.T + TT - 1) / TT;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
+    const int col0 = threadIdx.x % G::LW;
+    const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
+    const int q = split * G::STRIPES + stripe;
+    const int nG = (np + 7) / 8 * (8 / U), nW = a.splits * G::STRIPES;
+    const int sb = (int) ((long) nG * q / nW) * U, se = (int) ((long) nG * (q + 1) / nW) * U;
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
+
+#pragma unroll 1
+    for (int c = 0; c < G::CPT; c++) {
+        const int col = col0 + c * G::LW;
+        v2f_t acc[TT][2];
+#pragma unroll
+        for (int j = 0; j < TT; j++) { acc[j][0] = v2f_t{0.f, 0.f}; acc[j][1] = v2f_t{0.f, 0.f}; }
+        if (sb < se) {
+            // column 0 (packed bin 0) sits in lane 0 of ONE wave per stripe: only that wave pays for the operand selects
+            const bool wave_has_col0 = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(col) == 0 : true;
+            if (wave_has_col0) tile_run<N, TT, U, NT, true>(H4, X4, col, sb, se, j0, a.head, a.R, acc, col == 0);
+            else               tile_run<N, TT, U, NT, false>(H4, X4, col, sb, se, j0, a.head, a.R, acc, false);
+        }
+#pragma unroll
+        for (int j = 0; j < TT; j++) {
+            if (j0 + j < a.T) {
+                float4 *dst = reinterpret_cast<float4 *>(a.part + (((size_t) s * a.T + j0 + j) * a.nq + q) * M);
+                dst[col] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ifft_ola_run: inverse FFT + overlap-add of the time-tiled path without the duplicate transform.
+// A workgroup owns NB consecutive output blocks of one stream and runs NB + 1 waves: wave w transforms block
+// jb - 1 + w (wave 0: the predecessor of the run, needed only for its tail; for jb = 0 it fetches the saved
+// overlap instead); after one barrier wave w >= 1 adds its own first half to the second half its neighbour left
+// in LDS (reference fp/convolution.cpp:209-213).  NB + 1 transforms per NB blocks (round 2: 2 NB), critical
+// path one transform.  grid = S * ceil(T / NB).
+// ---------------------------------------------------------------------------------------------
+// blocks per workgroup: LDS = (NB + 1) * N * 4 + 3 N * 2 bytes must stay under the 64 KiB static limit
+template <int N> struct OlaGeom { static constexpr int NB = N <= 1024 ? 4 : N == 2048 ? 2 : 1; };
+
+template <int N, int NB>
+__global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, int S)
+{
+    constexpr int M = N / 2;
+    constexpr int VPL = M > kWave ? M / kWave : 1;     // samples per lane of a half block (B <= M)
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[NB + 1][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int runs = (a.T + NB - 1) / NB;
+    const int s = blockIdx.x / runs, jb = (blockIdx.x % runs) * NB;
+    const int j = jb - 1 + wave;                       // this wave's block
+    const bool live = j < a.T && (j >= 0);
+    const float scale = 1.0f / (float) N;
+    float2 *buf = l_buf[wave];
+    float *yw = reinterpret_cast<float *>(buf);
+    TwiddleStage<N, kWave * (NB + 1)> tws;
+    tws.load(a.tw);
+    float ov[VPL];
+    if (j < 0) {                                       // wave 0 of the first run: the overlap saved by the previous call
+        const float *o = a.ovl + (size_t) s * a.B;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) ov[i] = o[min(lane + i * kWave, a.B - 1)];
+    }
+    if (live) wave_sum_rows<N>(a.part + ((size_t) s * a.T + j) * a.nq * M, a.nq, buf, lane);
+    tws.store(l_tw);
+    __syncthreads();
+    if (live) {
+        wave_split_inverse<M>(buf, l_tw, lane);
+        wave_fft<M, true>(buf, l_tw, lane);
+    } else if (j < 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int n = lane + i * kWave;
+            if (n < a.B) yw[a.B + n] = ov[i] * (float) N;     // as an unscaled tail, like the transformed ones
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const float *y = reinterpret_cast<const float *>(buf);
+    if (wave >= 1) {
+        const float *yp = reinterpret_cast<const float *>(l_buf[wave - 1]);
+        float *out = a.out + (size_t) s * a.out_stride + (size_t) j * a.B;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int n = lane + i * kWave;
+            if (n < a.B) out[n] = y[n] * scale + yp[a.B + n] * scale;
+        }
+    }
+    if (j == a.T - 1) {
+        float *on = a.ovl_next + (size_t) s * a.B;
+        for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
+    }
+}
+
+}  // namespace irb

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <vector>
 
@@ -29,8 +30,10 @@ struct irb_rt {
     irb_fdl *eng = nullptr;
     std::vector<float> ir;                    // IRtoConvolve (:411-414)
     std::vector<float> inBlock;               // [C][B] block being filled (:421-426)
-    std::vector<float> ready;                 // [nb][C][B] complete blocks of this call
-    std::vector<float> conv;                  // [C][B] one processed block
+    std::vector<float> ready;                 // [C][maxBlocks*B] complete blocks of this call, stream-major
+    std::vector<float> conv;                  // [C][maxBlocks*B] the processed blocks
+    int maxBlocks = 1;                        // most complete blocks one callback can hold: (H + B - 1) / B + 1
+    unsigned long long callbacks = 0;
     std::vector<float> outRing;               // [outSize][C][H] (:210)
     std::vector<const float *> inp;           // per-channel pointers handed to the engine (sized at create)
     std::vector<float *> outp;
@@ -65,7 +68,6 @@ int irb_rt_create(int device, int channels, int block, int ir_ring_len, irb_rt *
     p->ir.assign((size_t) std::max(ir_ring_len, p->P * block), 0.0f);
     p->ir[ir_ring_len > 100 ? 100 : 0] = 1.0f;
     p->inBlock.assign((size_t) channels * block, 0.0f);
-    p->conv.assign((size_t) channels * block, 0.0f);
     p->inp.assign((size_t) channels, nullptr);
     p->outp.assign((size_t) channels, nullptr);
     *out = p;
@@ -104,17 +106,21 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     if (p->outputSampleIndex >= p->H) p->outputSampleIndex = 0;                 // reference: left as is (UB if too large)
     std::fill(p->inBlock.begin(), p->inBlock.end(), 0.0f);
     // every buffer the audio callback touches is sized here: process_block never allocates
-    p->ready.clear();
-    p->ready.reserve(((size_t) p->H / p->B + 2) * p->C * p->B);
+    p->maxBlocks = (p->H + p->B - 1) / p->B + 1;
+    p->ready.assign((size_t) p->C * p->maxBlocks * p->B, 0.0f);
+    p->conv.assign((size_t) p->C * p->maxBlocks * p->B, 0.0f);
     p->irWriteIndex = 0;                                                        // :226 clearAndResize
     irb_fdl_destroy(p->eng);
     p->eng = nullptr;
     irb_fdl_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.device = p->device; cfg.n_instances = 1; cfg.channels = p->C; cfg.block = p->B;
-    cfg.max_ir_len = p->P * p->B; cfg.max_blocks_per_call = 1;
-    cfg.flags = IRB_FDL_HOST_IO;          // one block per callback: kernels read / write the pinned staging directly (no copy round trips)
-    if (const char *v = std::getenv("IRB_RT_HOST_IO")) { if (std::atoi(v) == 0) cfg.flags = 0; }     // A/B
+    cfg.max_ir_len = p->P * p->B; cfg.max_blocks_per_call = p->maxBlocks;
+    // the callback's blocks are stepped one by one (rolling IR refresh between them) but enqueued together; kernels read /
+    // write the pinned staging directly (no copy round trips)
+    cfg.flags = IRB_FDL_HOST_IO | IRB_FDL_STEPWISE;
+    if (const char *v = std::getenv("IRB_RT_HOST_IO")) { if (std::atoi(v) == 0) cfg.flags &= ~IRB_FDL_HOST_IO; }     // A/B
+    if (const char *v = std::getenv("IRB_RT_ONE_LAUNCH")) { if (std::atoi(v) == 0) cfg.flags |= IRB_FDL_NO_RT_KERNEL; }   // A/B
     return irb_fdl_create(&cfg, &p->eng);
 }
 
@@ -143,6 +149,14 @@ int irb_rt_process_block_bypassed(irb_rt *p, float *const *buffer, int n)       
     return IRB_OK;
 }
 
+int irb_rt_counters(const irb_rt *p, unsigned long long *callbacks, unsigned long long *launches, unsigned long long *waits,
+                    unsigned long long *copies)
+{
+    if (!p || !p->eng) return irb_set_error_(IRB_ERR_STATE, "counters before prepare_to_play");
+    if (callbacks) *callbacks = p->callbacks;
+    return irb_fdl_get_counters(p->eng, launches, waits, copies);
+}
+
 int irb_rt_latency(const irb_rt *p) { return p ? p->latency : 0; }
 int irb_rt_partitions(const irb_rt *p) { return p ? p->P : 0; }
 
@@ -155,47 +169,84 @@ int irb_rt_process_block(irb_rt *p, float *const *buffer, int n)                
     const int C = p->C, B = p->B, H = p->H;
     for (int c = 0; c < C; c++) if (!buffer[c]) return irb_set_error_(IRB_ERR_ARG, "null channel pointer");
 
-    // :421-445 collect host samples into blocks of B
-    p->ready.clear();
-    for (int sample = 0; sample < n; sample++) {
-        for (int c = 0; c < C; c++) p->inBlock[(size_t) c * B + p->inputBufferSampleIndex] = buffer[c][sample];
-        if (++p->inputBufferSampleIndex >= B) {
-            p->ready.insert(p->ready.end(), p->inBlock.begin(), p->inBlock.end());
+    // :421-445 collect host samples into blocks of B (run-wise copies; the reference moves one sample at a time)
+    const size_t chan = (size_t) p->maxBlocks * B;          // per-channel pitch of ready / conv
+    int nb = 0;
+    for (int pos = 0; pos < n;) {
+        const int take = std::min(B - p->inputBufferSampleIndex, n - pos);
+        for (int c = 0; c < C; c++)
+            std::memcpy(p->inBlock.data() + (size_t) c * B + p->inputBufferSampleIndex, buffer[c] + pos, sizeof(float) * take);
+        pos += take;
+        p->inputBufferSampleIndex += take;
+        if (p->inputBufferSampleIndex >= B) {
+            for (int c = 0; c < C; c++)
+                std::memcpy(p->ready.data() + c * chan + (size_t) nb * B, p->inBlock.data() + (size_t) c * B, sizeof(float) * B);
             std::fill(p->inBlock.begin(), p->inBlock.end(), 0.0f);
             p->inputBufferSampleIndex = 0;
+            nb++;
         }
     }
 
-    // :452-518 one FDL step per complete block, then :525-543 into the output ring
-    const size_t nb = p->ready.size() / ((size_t) C * B);
-    std::vector<const float *> &inp = p->inp;
-    std::vector<float *> &outp = p->outp;
-    for (size_t j = 0; j < nb; j++) {
-        int rc = irb_fdl_set_ir_partition(p->eng, 0, p->irWriteIndex, p->ir.data() + (size_t) p->irWriteIndex * B);   // :455-461
+    // :452-518 the rolling IR refresh + one FDL step per complete block -- ONE engine call (one wait) for all of them --
+    // then :525-543 into the output ring
+    if (nb > 0) {
+        for (int c = 0; c < C; c++) { p->inp[c] = p->ready.data() + c * chan; p->outp[c] = p->conv.data() + c * chan; }
+        int rc = irb_fdl_process_refresh(p->eng, 0, p->inp.data(), p->outp.data(), nb, p->ir.data(), p->irWriteIndex);   // :455-461
         if (rc != IRB_OK) return rc;
-        if (++p->irWriteIndex >= p->P) p->irWriteIndex = 0;
-        for (int c = 0; c < C; c++) { inp[c] = p->ready.data() + (j * C + c) * B; outp[c] = p->conv.data() + (size_t) c * B; }
-        rc = irb_fdl_process(p->eng, inp.data(), outp.data(), 1);
-        if (rc != IRB_OK) return rc;
-        for (int sample = 0; sample < B; sample++) {
+        p->irWriteIndex = (p->irWriteIndex + nb) % p->P;
+        for (int pos = 0; pos < nb * B;) {
             float *w = p->outRing.data() + (size_t) p->outWr * C * H;
             if (p->outputBufferSampleIndex == 0) std::fill(w, w + (size_t) C * H, 0.0f);
-            for (int c = 0; c < C; c++) w[(size_t) c * H + p->outputBufferSampleIndex] = p->conv[(size_t) c * B + sample];
-            if (++p->outputBufferSampleIndex >= H) {
+            const int take = std::min(H - p->outputBufferSampleIndex, nb * B - pos);
+            for (int c = 0; c < C; c++)
+                std::memcpy(w + (size_t) c * H + p->outputBufferSampleIndex, p->conv.data() + c * chan + pos, sizeof(float) * take);
+            pos += take;
+            p->outputBufferSampleIndex += take;
+            if (p->outputBufferSampleIndex >= H) {
                 if (++p->outWr >= p->outSize) p->outWr = 0;
                 p->outputBufferSampleIndex = 0;
             }
         }
     }
+    p->callbacks++;
 
     // :550-560 output ring -> host buffer
-    for (int sample = 0; sample < n; sample++) {
+    for (int pos = 0; pos < n;) {
         const float *r = p->outRing.data() + (size_t) p->outRd * C * H;
-        for (int c = 0; c < C; c++) buffer[c][sample] = r[(size_t) c * H + p->outputSampleIndex];
-        if (++p->outputSampleIndex >= H) {
+        const int take = std::min(H - p->outputSampleIndex, n - pos);
+        for (int c = 0; c < C; c++) std::memcpy(buffer[c] + pos, r + (size_t) c * H + p->outputSampleIndex, sizeof(float) * take);
+        pos += take;
+        p->outputSampleIndex += take;
+        if (p->outputSampleIndex >= H) {
             if (++p->outRd >= p->outSize) p->outRd = 0;
             p->outputSampleIndex = 0;
         }
+    }
+    return IRB_OK;
+}
+
+// Measurement support: n_callbacks host callbacks of n samples per channel (white noise, in place, as a plug-in host
+// would call processBlock) timed one by one on the calling thread with the monotonic clock.
+int irb_rt_time_callbacks(irb_rt *p, int n, int n_callbacks, float *us_out)
+{
+    if (!p || !us_out) return irb_set_error_(IRB_ERR_ARG, "null argument");
+    if (!p->eng) return irb_set_error_(IRB_ERR_STATE, "time_callbacks before prepare_to_play");
+    if (n < 1 || n_callbacks < 1) return irb_set_error_(IRB_ERR_ARG, "n and n_callbacks must be >= 1");
+    std::vector<float> store((size_t) p->C * n);
+    std::vector<float *> ch((size_t) p->C);
+    for (int c = 0; c < p->C; c++) ch[c] = store.data() + (size_t) c * n;
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < n_callbacks; k++) {
+        for (float &v : store) {                       // fresh noise every callback (xorshift; values in [-1, 1))
+            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+            v = (float) ((double) (rng >> 40) / 8388608.0 - 1.0);
+        }
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        int rc = irb_rt_process_block(p, ch.data(), n);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (rc != IRB_OK) return rc;
+        us_out[k] = (float) ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3);
     }
     return IRB_OK;
 }

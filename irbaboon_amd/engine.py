@@ -78,6 +78,23 @@ class FdlEngine:
         check(_lib.lib().irb_fdl_process(self._h, planar_ptrs(x), planar_ptrs(y), x.shape[1] // self.block))
         return y
 
+    def process_refresh(self, x, ir, first_partition, instance=0):
+        """The real-time callback body (irb_fdl_process_refresh): block j of x re-derives partition (first_partition + j) mod P
+        of `instance` from the time-domain `ir` (P*block samples) before it is stepped.  One wait for the whole call."""
+        x = np.ascontiguousarray(x, np.float32)
+        ir = np.ascontiguousarray(ir, np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.streams and x.shape[1] % self.block == 0
+        assert ir.size >= self.info.partitions * self.block
+        y = np.empty_like(x)
+        check(_lib.lib().irb_fdl_process_refresh(self._h, instance, planar_ptrs(x), planar_ptrs(y), x.shape[1] // self.block,
+                                                 ir.ctypes.data_as(fp), first_partition))
+        return y
+
+    def counters(self):
+        v = [C.c_ulonglong() for _ in range(3)]
+        check(_lib.lib().irb_fdl_get_counters(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
     def process_packed(self, x, out=None):
         """x: one C-contiguous float32 array [streams][n_blocks*block]; no per-stream packing on the host.
         Use pinned_empty() buffers for PCIe-speed transfers."""

@@ -44,6 +44,19 @@ class RtConvolver:
         assert buffer.dtype == np.float32 and buffer.flags.c_contiguous and buffer.shape[0] == self.channels
         check(_lib.lib().irb_rt_process_block_bypassed(self._h, planar_ptrs(buffer), buffer.shape[1]))
 
+    def time_callbacks(self, n, n_callbacks):
+        """Wall time in microseconds of each of n_callbacks processBlock calls of n samples per channel on white noise,
+        timed in C on the calling thread (irb_rt_time_callbacks)."""
+        us = np.empty(n_callbacks, np.float32)
+        check(_lib.lib().irb_rt_time_callbacks(self._h, n, n_callbacks, us.ctypes.data_as(fp)))
+        return us
+
+    def counters(self):
+        """(callbacks, kernel launches, blocking waits, copy commands) since prepareToPlay."""
+        v = [C.c_ulonglong() for _ in range(4)]
+        check(_lib.lib().irb_rt_counters(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
     @property
     def latency(self):
         return _lib.lib().irb_rt_latency(self._h)

@@ -156,6 +156,74 @@ def test_rt_adapter_matches_oracle(host_block):
         gpu.close()
 
 
+@pytest.mark.parametrize("host_block", [64, 100, 256, 512, 1024])
+def test_rt_one_launch_callback_matches_two_launch_path_and_oracle(monkeypatch, host_block):
+    """The callback as ONE kernel launch (k_rt_pair: rolling IR refresh + every block of the callback + completion word,
+    Source/PluginProcessor.cpp:452-518) against the refresh-launch + step-launch sequence (IRB_RT_ONE_LAUNCH=0) and, for
+    host blocks the reference handles causally (<= 256), against the restated processBlock -- with the IR replaced in
+    mid-stream, so that the FDL meets a mixture of old and new partitions exactly as the reference's does."""
+    irs = [decaying_ir(5, 8 * 256), decaying_ir(6, 8 * 256)[::-1].copy()]
+    n_cb = max(24, 256 * 40 // host_block)
+    x = np.stack([white_noise(43, n_cb * host_block), white_noise(44, n_cb * host_block)])
+    outs, counts = [], []
+    for one in ("1", "0"):
+        monkeypatch.setenv("IRB_RT_ONE_LAUNCH", one)
+        gpu = RtConvolver(2, 256, 2048)
+        gpu.prepareToPlay(host_block)
+        ref = oracle.RtProcessor(2, 256, 2048)
+        ref.prepare_to_play(host_block)
+        y, yr = np.empty_like(x), np.empty_like(x)
+        for k in range(n_cb):
+            if k in (3, n_cb // 2):
+                gpu.setIR(irs[k == 3])
+                ref.set_ir(irs[k == 3])
+            a = np.ascontiguousarray(x[:, k * host_block:(k + 1) * host_block])
+            b = a.copy()
+            gpu.processBlock(a)
+            y[:, k * host_block:(k + 1) * host_block] = a
+            if host_block <= 256:
+                ref.process_block(b)
+                yr[:, k * host_block:(k + 1) * host_block] = b
+            if k == 7:
+                c0 = gpu.counters()                     # steady state from here on (set-up waits and uploads are behind)
+        if host_block <= 256:
+            for c in range(2):
+                assert rel_rms(y[c], yr[c]) < RMS_TOL
+        c1 = gpu.counters()
+        counts.append(((c1[1] - c0[1]) / (c1[0] - c0[0]), (c1[2] - c0[2]) / (c1[0] - c0[0])))
+        outs.append(y)
+        gpu.close()
+    assert rel_rms(outs[0], outs[1]) < 2e-6 and np.abs(outs[0]).max() > 0
+    blocks_per_cb = host_block / 256
+    assert counts[0][0] <= min(1.0, blocks_per_cb) + 0.05 and counts[0][1] <= 1.05     # one launch, one wait per callback with work
+    assert counts[1][0] >= 2 * blocks_per_cb - 0.05                                  # the A/B arm: refresh + step per block
+
+
+@pytest.mark.parametrize("case", [(2, 2, 128, 1024, 3), (1, 1, 256, 2048, 2), (1, 2, 256, 96000, 2), (1, 2, 2048, 8192, 1)],
+                         ids=lambda c: "I%d_C%d_B%d_Lh%d_nb%d" % c)
+def test_process_refresh_on_engine_shapes_without_the_rt_kernel(case):
+    """irb_fdl_process_refresh on shapes that do not qualify for the one-launch kernel (several instances, mono, a long IR
+    ring on the column-sliced path, B = 2048): refresh and step launches enqueued per block, one wait -- the same samples
+    as irb_fdl_set_ir_partition + irb_fdl_process block by block."""
+    I, C, B, Lh, nb = case
+    P = Lh // B
+    T = 3 * nb + 1
+    x = _streams(I, C, T * nb * B, 9700)
+    h = decaying_ir(9750, P * B)
+    with FdlEngine(I, C, B, Lh, max_blocks_per_call=nb, flags=_lib.HOST_IO | _lib.STEPWISE) as a, \
+         FdlEngine(I, C, B, Lh, max_blocks_per_call=1, flags=_lib.HOST_IO) as b:
+        ya, yb, part = [], [], 0
+        for k in range(T):
+            xs = x[:, k * nb * B:(k + 1) * nb * B]
+            ya.append(a.process_refresh(xs, h, part, instance=I - 1))
+            for j in range(nb):
+                b.set_ir_partition(I - 1, (part + j) % P, h[((part + j) % P) * B:((part + j) % P + 1) * B])
+                yb.append(b.process(xs[:, j * B:(j + 1) * B]))
+            part = (part + nb) % P
+        ya, yb = np.concatenate(ya, axis=1), np.concatenate(yb, axis=1)
+    assert np.array_equal(ya, yb) and np.abs(ya[(I - 1) * C:]).max() > 0
+
+
 def test_rt_adapter_host_block_larger_than_block_is_causal():
     """hostBlock 512 > 256: the reference's FDL ring is one slot short and feeds a future block to
     its last partition; the adapter keeps P past blocks, so it must equal the true
@@ -473,6 +541,34 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
             for i in range(I):
                 eng.set_ir(i, irs[i])
             outs.append(eng.process(x))
+    assert rel_rms(outs[0], outs[1]) < 2e-6
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
+
+
+@pytest.mark.parametrize("kernel", ["1", "2", "3", "4"], ids=["pk16x8", "pk16x4", "pk12x4", "pk8x8"])
+@pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 512, 6000, 16), (3, 1, 64, 900, 50),
+                                        (1, 2, 1024, 9000, 17), (1, 1, 2048, 9000, 5)])
+def test_packed_fma_tiled_kernels(monkeypatch, kernel, I, C, B, Lh, T):
+    """k_cmac_tiled_pk (v_pk_fma_f32, register-ring window; IRB_TILED_KERNEL 1..4 = tile shapes 16x8 / 16x4 / 12x4 / 8x8)
+    against round 2's k_cmac_tiled (IRB_TILED_KERNEL=0) and the oracle: calls that end inside a tile, partition
+    counts that are not a multiple of the ring period, packed bin 0, one call split in two (FDL history across calls)."""
+    x = _streams(I, C, T * B, 755)
+    irs = [np.stack([decaying_ir(760 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    outs = []
+    for k in (kernel, "0"):
+        monkeypatch.setenv("IRB_TILED_KERNEL", k)
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            y = eng.process(x)
+            eng.reset()
+            cut = (T // 3) * B                         # the same signal as two calls of different length
+            y2 = np.concatenate([eng.process(x[:, :cut]), eng.process(x[:, cut:])], axis=1) if cut else y
+            assert rel_rms(y2, y) < 2e-6
+            outs.append(y)
     assert rel_rms(outs[0], outs[1]) < 2e-6
     for i in range(I):
         ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)

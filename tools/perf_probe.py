@@ -124,6 +124,21 @@ def rt(host_block=256, n=2000):
           f"(deadline {host_block/48000*1e6:.0f} us at 48 kHz)")
 
 
+def rtc(host_block=256, n=3000):
+    """the same callbacks timed in C (irb_rt_time_callbacks): what bench.py's rt_processBlock entry reports"""
+    from irbaboon_amd import RtConvolver
+    r = RtConvolver(2, 256, 2048)
+    r.prepareToPlay(host_block)
+    r.time_callbacks(host_block, 200)
+    c0 = r.counters()
+    ts = r.time_callbacks(host_block, n)
+    c1 = r.counters()
+    cb = c1[0] - c0[0]
+    env = {k: v for k, v in os.environ.items() if k.startswith("IRB_")}
+    print(f"rt adapter (C loop) hostBlock={host_block} {env}: median {np.median(ts):.1f} us, p99 {np.percentile(ts, 99):.1f} us, max {ts.max():.1f} us; "
+          f"per callback: {(c1[1]-c0[1])/cb:.2f} launches, {(c1[2]-c0[2])/cb:.2f} waits, {(c1[3]-c0[3])/cb:.2f} copies")
+
+
 def hostapi(I=2048, B=256, Lh=96000, T=1, reps=30):
     """PCIe-inclusive rate through the host-pointer API (irb_fdl_process): pack, H2D, kernels, D2H, unpack"""
     import ctypes as C
@@ -191,4 +206,4 @@ def lfft(logn=20, batch=1, reps=50):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(a) for a in sys.argv[2:]]
-    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "hostapi": hostapi, "few": few, "twoqueue": twoqueue}[mode](*args)
+    {"offline": offline, "single": single, "lfft": lfft, "stereo": stereo, "rt": rt, "rtc": rtc, "hostapi": hostapi, "few": few, "twoqueue": twoqueue}[mode](*args)
