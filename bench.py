@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 B, LH = 256, 96000          # configs[1]: block 256, 2 s IR at 48 kHz
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak fp32 (vector); tools/valu_peak.hip measures 130 / 145 at 2 / 4 waves per SIMD
 NB = 8                      # distinct input blocks kept resident per instance (cycled)
 
 
@@ -215,9 +216,23 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
         di, do, st = e.device_io()
         e.upload(di, np.stack([white_noise(3000 + s, T * Bk) for s in range(I * C)]))
         ms = _timed_calls(e, di, do, st, T, reps)
-        alg = I * C * T * e.info.algorithmic_bytes_per_block_step
-        res[name] = {"Msamples_per_s": round(I * C * T * Bk / ms / 1e3, 1), "ms_per_call": round(ms, 4), "blocks_per_call": T,
-                     "splits": e.info.splits, "algorithmic_GBps_streaming_model": round(alg / ms / 1e6, 1), "note": note}
+        ent = {"Msamples_per_s": round(I * C * T * Bk / ms / 1e3, 1), "ms_per_call": round(ms, 4), "blocks_per_call": T,
+               "splits": e.info.splits, "note": note}
+        if T == 1:      # streaming: SURVEY 8d bytes per stream-step are what one launch moves
+            alg = I * C * e.info.algorithmic_bytes_per_block_step
+            if C == 2 and (ir_ch or C) == 1:            # paired kernel: each H row is loaded once for both channels
+                alg = I * (12.0 * e.info.partitions * e.info.fft_len + 32.0 * Bk)
+                ent["algorithmic_bytes_model"] = "12*P*N + 32*B per instance-step (H row shared by both channels)"
+            ent["algorithmic_GBps"] = round(alg / ms / 1e6, 1)
+            ent["frac_of_hbm_peak"] = round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)
+        else:           # time-tiled: rows are reused in registers, the call is fp32-VALU bound: flops of the complex MAC
+            flops = 8.0 * e.info.partitions * (e.info.fft_len // 2) * T * I * C
+            ent["fp32_flops"] = flops
+            ent["TFLOPs"] = round(flops / ms / 1e9, 2)
+            ent["frac_of_157.3"] = round(flops / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
+            ent["roofline_note"] = ("whole call (forward FFTs + MAC + inverse FFTs / overlap-add) against the fp32 vector peak; "
+                                    "MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, T blocks")
+        res[name] = ent
         e.close()
 
     run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 10,
@@ -232,8 +247,46 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     run("rt_layout_1024_stereo_instances_mono_ir", 1024, 2, 256, 96000, 1, 100,
         "stereo audio, IR channel 0 for both channels (the plug-in's real-time layout, Source/PluginProcessor.cpp:485): "
         "paired kernel loads each IR row once for both channels (3 rows per partition instead of 4)", ir_ch=1)
+    res["rt_processBlock"] = rt_process_block(dev, np)
     res.update(config5(dev, np))
     return res
+
+
+def rt_process_block(dev, np):
+    """The plug-in's callback (IRCAP_IDLE branch of processBlock, Source/PluginProcessor.cpp:408-562) through the adapter's
+    C ABI: stereo, B=256, 8 partitions (2048-sample IR ring), rolling IR refresh, host blocks of 256 and 512 samples.
+    Callbacks are timed one by one INSIDE the library (irb_rt_time_callbacks: monotonic clock around irb_rt_process_block
+    on the calling thread, fresh noise every callback), launches / waits / copies counted by the engine."""
+    from irbaboon_amd import RtConvolver
+    from irbaboon_amd.synth import decaying_ir
+    out = {}
+    for hb in (256, 512):
+        r = RtConvolver(2, 256, 2048, device=dev)
+        r.prepareToPlay(hb)
+        r.setIR(decaying_ir(31000, 2048))
+        r.time_callbacks(hb, 300)                       # warm-up: every partition refreshed, clocks up
+        c0 = r.counters()
+        us = r.time_callbacks(hb, 3000)
+        c1 = r.counters()
+        cb = c1[0] - c0[0]
+        out[f"host_block_{hb}"] = {
+            "callbacks": int(cb), "median_us": round(float(np.median(us)), 2), "p99_us": round(float(np.percentile(us, 99)), 2),
+            "max_us": round(float(us.max()), 2), "launches_per_callback": round((c1[1] - c0[1]) / cb, 3),
+            "waits_per_callback": round((c1[2] - c0[2]) / cb, 3), "copies_per_callback": round((c1[3] - c0[3]) / cb, 3),
+            "deadline_us_at_48k": round(hb / 48000 * 1e6, 1), "Msamples_per_s": round(2 * hb / float(np.median(us)), 2)}
+        r.close()
+    out["note"] = ("RtConvolver (irb_rt_*): stereo, B=256, P=8, IR channel 0 for both channels, one IR partition re-derived per block; "
+                   "blocks and IR samples in mapped pinned host memory, one k_rt_pair launch per callback, completion by a "
+                   "host-mapped word; wall time per callback on the host, PCIe included")
+    return out
+
+
+def run_environment():
+    """Which library and which tuning overrides produced this line (a stale IRB_* variable changes the kernel a
+    bench line exercises; the line must say so)."""
+    from irbaboon_amd import _lib
+    return {"library": os.path.relpath(_lib.SO_PATH, ROOT) if _lib.SO_PATH.startswith(ROOT) else _lib.SO_PATH,
+            "irb_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("IRB_")}}
 
 
 def config5(dev, np):
@@ -404,7 +457,11 @@ def main():
         ev_ms_max, ev_ms_min = max(ev_ms), min(ev_ms)
 
     total_samples = float(I) * world * B * K
-    value = total_samples / wall / 1e6
+    # `value`: all ranks' samples over the slowest device's K steps as its own hipEvents saw them (recorded on the stream the
+    # kernels run on, before the first and after the last of the K launches).  The host wall clock around the same region,
+    # barrier and device syncs included, is reported beside it; with 8 engines in one process it carries 8 sync calls.
+    step_ms = ev_ms_max / K
+    value = total_samples / (ev_ms_max * 1e-3) / 1e6
     three = bool(os.environ.get("IRB_SPLIT_3LAUNCH", "0") not in ("", "0"))
     launches_per_step = 1 if (info.splits <= 1 or not three) else 3
     kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step; the slowest device
@@ -425,7 +482,9 @@ def main():
     out = {
         "metric": "Msamples/s (48 kHz, 256-blk, 2 s IR); achieved HBM GB/s vs roofline",
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(step_ms, 4), "ms_per_step_wall": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "n_gpus_visible": ndev, "timing": "max over devices of hipEvent time around the K timed launches (ms_per_step); host wall clock "
+                                          "around the same region incl. barrier and syncs (ms_per_step_wall)",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1] geometry (mono, B={B}, Lh={LH}, P={info.partitions}, N={info.fft_len}) "
                                f"x {I} independent instances per GPU, streaming: 1 block per instance per step",
@@ -445,6 +504,7 @@ def main():
     }
     if rehearsal:
         out["rehearsal"] = rehearsal
+    out["environment"] = run_environment()
 
     solo = rank == 0 and world == 1
     if solo and not args.no_single:

@@ -74,8 +74,8 @@ double irb_sweep_freq_at_sample_index(int index, double duration_secs, double sa
 int    irb_sweep_lin_fadeout(double *sweep, int n, int index);
 
 /* The one-shot entry points (here and irb_convolve_periodic) keep the calling thread's most recent FFT plan /
- * engine (device buffers, twiddle tables, stream) for reuse; this releases them (a thread that used one-shot
- * calls should call it before it exits: the cache is per thread and is not freed automatically).  No reference counterpart
+ * engine (device buffers, twiddle tables, stream) for reuse; this releases them now.  The cache is per thread and is
+ * also freed when its thread exits (a thread-local guard object), so a host thread pool does not leak.  No reference counterpart
  * (the reference constructs a dsp::FFT per call, fp/tools.cpp:331,359). */
 void irb_release_cached_plans(void);
 

@@ -94,7 +94,10 @@ int  irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info);
  *   ir_channels 2, channels 2 -> audio channel c uses ir[c]
  *   ir_channels 2, channels 1 -> (ir[0]+ir[1])/2 (tools::sumToMono, fp/tools.cpp:14-30)
  * ir: host pointers, planar [ir_channels][len], len <= max_ir_len.  Takes effect
- * for all partitions at once (the whole-IR behaviour of convolvePeriodic).      */
+ * for all partitions at once (the whole-IR behaviour of convolvePeriodic).  The
+ * samples are copied before the call returns; the transform is enqueued on the
+ * handle's stream (ordered before every later process call), so loading the IRs of
+ * thousands of instances does not wait for the GPU once per instance.             */
 int  irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_channels, int len);
 
 /* Replaces: the rolling one-partition-per-block refresh of the real-time path
@@ -157,7 +160,8 @@ int  irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long st
 /* Wait for everything enqueued on the handle's stream (no reference counterpart: the reference is synchronous).
  * Returns IRB_ERR_STATE if a step kernel's bounded in-kernel wait gave up since the last check (multi-workgroup steps
  * of few streams hand partial spectra over inside one launch; a wait is abandoned after 50 ms instead of hanging the
- * GPU, and the blocks of that step are then invalid).  The blocking process calls report the same condition. */
+ * GPU; the affected stream then writes neither output nor overlap for that block).  The blocking process calls report
+ * the same condition.  After IRB_ERR_STATE call irb_fdl_reset before relying on the handle's output again.           */
 int  irb_fdl_synchronize(irb_fdl *h);
 
 /* Stream-ordered timing on the handle's stream (hipEvent): `mark` records event
@@ -179,7 +183,9 @@ int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_float
  * audio: planar [audio_ch][La]; ir: planar [ir_ch][Lh]; out: planar
  * [audio_ch][La+Lh-1].  keep_reference_tail != 0 reproduces the reference's
  * dropped tail (only (floor(La/B)+P)*B samples are written, the rest stay 0,
- * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.        */
+ * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.
+ * The calling thread's engine (device buffers, pinned staging, stream) is kept for the next call of a similar size;
+ * it is freed by irb_release_cached_plans() (irb_deconv.h) or when the thread exits.        */
 int  irb_convolve_periodic(int device,
                            const float *const *audio, int audio_ch, int La,
                            const float *const *ir, int ir_ch, int Lh,

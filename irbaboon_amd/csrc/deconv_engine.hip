@@ -189,13 +189,16 @@ int complex_fft(irb_lfft *p, const float2 *src, float2 *tmp, float2 *dst, int ba
 
 // One-shot entry points (fftTransform, deconvolve, ...) reuse the most recent plan of the calling thread when
 // device, length and batch capacity fit: plan creation (stream, tables, five hipMallocs) costs far more than a
-// 2^20-point transform.  The cached plan is released by irb_release_cached_plans() (or with the process).
+// 2^20-point transform.  The cached plan is released by irb_release_cached_plans(), or by the cache's destructor when
+// the calling thread exits (thread-local objects of the main thread are destroyed at exit() before the HIP runtime's
+// static teardown; a pool thread of a plug-in host frees its plan when it ends).
+extern "C" void irb_lfft_destroy(irb_lfft *p);
 struct PlanCache {
-    irb_lfft *plan = nullptr;      // deliberately no destructor: at process exit the HIP runtime may already be gone
+    irb_lfft *plan = nullptr;
+    ~PlanCache() { if (plan) { irb_lfft_destroy(plan); plan = nullptr; } }
 };
 thread_local PlanCache g_cache;
 
-extern "C" void irb_lfft_destroy(irb_lfft *p);
 extern "C" int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);
 
 int cached_plan(int device, int N, int batch, irb_lfft **out)

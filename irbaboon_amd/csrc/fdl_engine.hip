@@ -54,7 +54,7 @@ struct irb_fdl {
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
     int tiled_splits_override = 0;           // tuning: IRB_TILED_SPLITS, read once at create
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
-    int tiled_kernel = 1;                    // time-tiled MAC: 0 k_cmac_tiled<N,8> (round 2), 1..3 k_cmac_tiled_pk variants (IRB_TILED_KERNEL)
+    int tiled_kernel = 1;                    // time-tiled MAC: 1 k_cmac_tiled_pk (16 outputs x 8 partitions per step), 0 round 2's k_cmac_tiled<N,8> (IRB_TILED_KERNEL: A/B, tests)
     int tileTT = 16;                         // outputs per time tile of that kernel
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
@@ -67,6 +67,7 @@ struct irb_fdl {
     unsigned *h_done = nullptr, *d_done = nullptr;       // host-mapped completion word of the one-launch real-time callback (k_rt_pair)
     unsigned done_seq = 0;
     bool stepwise = false;                   // IRB_FDL_STEPWISE: a call of n blocks = n one-block steps, ring of P slots
+    long long cols_launches = 0, debug_drop_at = 0;   // IRB_DEBUG_DROP_GRANULES=n (tests): the n-th column-sliced launch loses one producer's granules
     unsigned long long n_launches = 0, n_waits = 0, n_copies = 0;   // what the host asked of the runtime since create (irb_fdl_get_counters)
     int ovl_cur = 0;                         // which half of d_ovl holds the live overlap
     size_t part_rows = 0;                    // capacity of d_part in spectrum rows
@@ -79,7 +80,13 @@ struct irb_fdl {
     int2 *d_stream_info = nullptr;          // [S] {IR set, partitions in use}: what the kernels read
     unsigned *d_tickets = nullptr;           // [S] arrival counters of k_step_split
     float *h_io = nullptr;                   // pinned: [S][Tmax*B]  (IRB_FDL_HOST_IO: [2][S][Tmax*B], input half + output half)
-    float *h_ir = nullptr;                   // pinned: [C][P*B]
+    float *h_ir = nullptr;                   // pinned: [2][C][P*B]: two staging slots, so that irb_fdl_set_ir never waits for the stream
+    hipEvent_t ev_ir[2] = {nullptr, nullptr}; // recorded behind the work that reads a slot
+    bool ir_used[2] = {false, false};
+    int ir_slot = 0;
+    int2 *h_info_slot = nullptr;             // pinned: [2][C] stream_info records of the instance a slot carries
+    bool part_busy = false;                  // a partition refresh enqueued since the last wait may still read slot 0 of h_ir
+    std::vector<char> part_slot_busy;        // which partition slots those refreshes used
     // IRB_FDL_HOST_IO: the kernels read blocks / IR partitions from, and write output blocks to, MAPPED pinned host memory
     // (zero copy): a blocking process call is pack + launch + wait, with no copy-engine round trips
     bool host_io = false;
@@ -92,7 +99,7 @@ namespace {
 
 // every wait on / copy through the runtime is counted (irb_fdl_get_counters: launches, waits and copies per callback are
 // part of what bench.py reports for the real-time path)
-inline hipError_t irb_sync(irb_fdl *h) { h->n_waits++; return hipStreamSynchronize(h->stream); }
+inline hipError_t irb_sync(irb_fdl *h) { h->n_waits++; h->part_busy = false; return hipStreamSynchronize(h->stream); }
 #define COPY_ASYNC(h_, ...)   ((h_)->n_copies++, hipMemcpyAsync(__VA_ARGS__))
 #define COPY2D_ASYNC(h_, ...) ((h_)->n_copies++, hipMemcpy2DAsync(__VA_ARGS__))
 
@@ -194,6 +201,7 @@ void choose_path(irb_fdl *h)
 }
 
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
+constexpr int kPadP = irb::kTilePeriod;       // H rows per set: P rounded up to this (a multiple of kTT); the extra rows stay zero
 
 // partition splits for a call of T blocks: enough workgroups to fill the chip, but every stripe keeps
 // at least two full window steps of partitions
@@ -201,9 +209,13 @@ int tiled_splits(const irb_fdl *h, int T)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     const int ntiles = (T + h->tileTT - 1) / h->tileTT;
-    const int by_work = std::max(1, (h->Ppad / kTT) / (stripes * 2));
+    const int by_work = h->tiled_kernel == 0 ? std::max(1, (h->Ppad / kTT) / (stripes * 2))
+                                             : std::max(1, (h->Ppad / kPadP) / stripes);     // every worker at least one ring period
     const long wgs = (long) h->S * ntiles;
-    const int by_chip = (int) std::max<long>(1, (h->tiled_chip_wgs + wgs - 1) / wgs);
+    // round-2 kernel: at least tiled_chip_wgs workgroups; packed-FMA kernels: as many splits as still fit the resident
+    // slots in ONE round (every split adds a partial spectrum per output that is written, flushed and read back)
+    const int by_chip = h->tiled_kernel == 0 ? (int) std::max<long>(1, (h->tiled_chip_wgs + wgs - 1) / wgs)
+                                             : (int) std::max<long>(1, h->tiled_chip_wgs / wgs);
     if (h->tiled_splits_override > 0) return std::max(1, std::min(by_work, h->tiled_splits_override));   // IRB_TILED_SPLITS
     return std::max(1, std::min(by_work, by_chip));
 }
@@ -213,7 +225,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     irb::StepArgs a;
     a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
-    a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0;
+    a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -227,9 +239,10 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
 #define LAUNCH_COLS_W(HO_)                                                                                        \
     if (h->colW == 4) { LAUNCH_COLS(4, HO_); } else if (h->colW == 16) { LAUNCH_COLS(16, HO_); } else { LAUNCH_COLS(64, HO_); }
 
-int launch_cols(irb_fdl *h, const irb::StepArgs &a)
+int launch_cols(irb_fdl *h, irb::StepArgs a)
 {
     h->n_launches++;
+    a.debug_drop = (++h->cols_launches == h->debug_drop_at) ? 1 : 0;
     if (h->cols_handoff == 2) { LAUNCH_COLS_W(2) }
     else if (h->cols_handoff == 1) { LAUNCH_COLS_W(1) }
     else { LAUNCH_COLS_W(0) }
@@ -243,6 +256,7 @@ int check_status(irb_fdl *h)
     if (h->h_status && *h->h_status) {
         *h->h_status = 0;
         *h->h_done = 0;
+        h->part_slot_busy.assign((size_t) h->P, 0);
         return fail(IRB_ERR_STATE, "in-kernel hand-off timed out (a producer workgroup never published its slice)");
     }
     return IRB_OK;
@@ -285,6 +299,7 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     const bool one_bin = h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
     if (one_bin) a.nq = a.splits * stripes1;
+    else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
     const int ntiles = one_bin ? (T + 15) / 16 : (T + h->tileTT - 1) / h->tileTT;
     const dim3 mac_grid(h->S * ntiles * a.splits), mac_block(irb::kThreads);
@@ -297,9 +312,6 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
         if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
         else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     }
-    else if (h->tiled_kernel == 2) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 4, 2><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    else if (h->tiled_kernel == 3) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 12, 4, 3><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    else if (h->tiled_kernel == 4) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 8, 4><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else          { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((T + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
@@ -319,10 +331,16 @@ int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int firs
     return IRB_OK;
 }
 
-int upload_maps(irb_fdl *h)
+// both channels of every instance share their IR set: the paired step kernels apply
+void update_pairing(irb_fdl *h)
 {
     h->pair = (h->C == 2) && !(h->flags & IRB_FDL_NO_PAIRING);
     for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
+}
+
+int upload_maps(irb_fdl *h)
+{
+    update_pairing(h);
     HIP_TRY(irb_sync(h));          // the pinned staging may still feed an earlier upload
     for (int s = 0; s < h->S; s++) h->h_info[s] = make_int2(h->h_set_of_stream[s], h->h_np_of_set[h->h_set_of_stream[s]]);
     HIP_TRY(COPY_ASYNC(h, h->d_stream_info, h->h_info, sizeof(int2) * h->S, hipMemcpyHostToDevice, h->stream));
@@ -331,7 +349,17 @@ int upload_maps(irb_fdl *h)
 
 }  // namespace
 
-namespace { thread_local irb_fdl *g_offline_engine = nullptr; }   // irb_convolve_periodic's cached engine (no destructor: see deconv_engine.hip)
+// irb_convolve_periodic's cached engine, one per calling thread.  The guard frees it (HBM, pinned staging, stream) when the
+// thread exits -- a plug-in host's pool thread that made one-shot calls must not leak an engine; irb_release_cached_plans()
+// is the explicit form.  (For the main thread this runs at exit(), before the HIP runtime's own static teardown.)
+extern "C" void irb_fdl_destroy(irb_fdl *h);
+namespace {
+struct OfflineEngineGuard {
+    irb_fdl *eng = nullptr;
+    ~OfflineEngineGuard() { if (eng) { irb_fdl_destroy(eng); eng = nullptr; } }
+};
+thread_local OfflineEngineGuard g_offline;
+}
 
 extern "C" {
 
@@ -351,6 +379,8 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->h_done) (void) hipHostFree(h->h_done);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
+    if (h->h_info_slot) (void) hipHostFree(h->h_info_slot);
+    for (auto &e : h->ev_ir) if (e) (void) hipEventDestroy(e);
     if (h->h_set_of_stream) (void) hipHostFree(h->h_set_of_stream);
     if (h->h_np_of_set) (void) hipHostFree(h->h_np_of_set);
     if (h->h_info) (void) hipHostFree(h->h_info);
@@ -377,7 +407,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->I = cfg->n_instances; h->C = cfg->channels; h->S = h->I * h->C;
     h->B = cfg->block; h->N = fft_len_for_block(h->B); h->M = h->N / 2;
     h->P = (cfg->max_ir_len + h->B - 1) / h->B;
-    h->Ppad = (h->P + kTT - 1) / kTT * kTT;
+    h->Ppad = (h->P + kPadP - 1) / kPadP * kPadP;
     h->Tmax = cfg->max_blocks_per_call;
     h->flags = cfg->flags;
     h->stepwise = (h->flags & IRB_FDL_STEPWISE) != 0 || h->Tmax == 1;
@@ -389,10 +419,13 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->tiled1 = h->nt;
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
     if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
+    h->debug_drop_at = env_int("IRB_DEBUG_DROP_GRANULES", 0);
     h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
-    if (h->tiled_kernel < 0 || h->tiled_kernel > 4) h->tiled_kernel = 1;
-    h->tileTT = (h->tiled_kernel == 0 || h->tiled_kernel == 4) ? kTT : h->tiled_kernel == 3 ? 12 : 16;
-    h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", 768));
+    if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
+    h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
+    // resident workgroups of the MAC kernel: 256 CUs x waves per SIMD its registers allow (2 / 2 / 3 / 4); round 2: 768 as a floor
+    const int slots[2] = {768, 512};
+    h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", slots[h->tiled_kernel]));
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };
@@ -406,7 +439,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc != IRB_OK) break;
         const size_t SM = (size_t) h->S * h->M;
-        if (!guard(dev_alloc(h, &h->d_H, SM * h->Ppad))) break;
+        if (!guard(dev_alloc(h, &h->d_H, SM * h->Ppad + (size_t) 8 * h->M))) break;     // + spare rows: the tiled MAC's last prefetch reads past the last set
         if (!guard(dev_alloc(h, &h->d_X, SM * h->R))) break;
         if (!guard(dev_alloc(h, &h->d_tw, (size_t) h->N))) break;
         {
@@ -427,7 +460,10 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         h->host_io = (h->flags & IRB_FDL_HOST_IO) != 0;
         const unsigned hflags = h->host_io ? hipHostMallocMapped : hipHostMallocDefault;
         if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_io), sizeof(float) * (size_t) (h->host_io ? 2 : 1) * h->S * h->Tmax * h->B, hflags)) != hipSuccess ||
-            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) h->C * h->P * h->B, hflags)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ir), sizeof(float) * (size_t) 2 * h->C * h->P * h->B, hflags)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_info_slot), sizeof(int2) * (size_t) 2 * h->C)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&h->ev_ir[0], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&h->ev_ir[1], hipEventDisableTiming)) != hipSuccess ||
             (h->host_io && (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hio), h->h_io, 0)) != hipSuccess) ||
             (h->host_io && (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hir), h->h_ir, 0)) != hipSuccess) ||
             (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_set_of_stream), sizeof(int) * h->S)) != hipSuccess ||
@@ -442,6 +478,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         }
         *h->h_status = 0;
         *h->h_done = 0;
+        h->part_slot_busy.assign((size_t) h->P, 0);
         // twiddles: W_N^j in double, rounded to float
         std::vector<float2> tw(h->N);
         for (int j = 0; j < h->N; j++) {
@@ -449,7 +486,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             tw[j] = make_float2((float) std::cos(ph), (float) std::sin(ph));
         }
         if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * h->N, hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * SM * h->Ppad, h->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * (SM * h->Ppad + (size_t) 8 * h->M), h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * (size_t) h->S, h->stream)) != hipSuccess ||
@@ -488,37 +525,46 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
         return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
     for (int c = 0; c < ir_channels; c++) if (!ir[c] && len > 0) return fail(IRB_ERR_ARG, "ir[%d] is null", c);
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(irb_sync(h));       // the pinned IR staging may still feed an earlier partition refresh
+    // Asynchronous: the IR goes through one of two pinned staging slots, and the only wait is for the work that read
+    // THIS slot two calls ago (an event, not the stream), so a host thread loading thousands of IRs keeps the copy
+    // engine and the FFT kernel busy instead of waiting three times per instance.
+    const int slot = h->ir_slot;
+    if (slot == 0 && h->part_busy) HIP_TRY(irb_sync(h));             // a rolling partition refresh may still read slot 0
+    if (h->ir_used[slot]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[slot])); }
+    float *stage = h->h_ir + (size_t) slot * h->C * h->P * h->B;
     const int np = (len + h->B - 1) / h->B;
     const int nrows = (ir_channels == 2 && h->C == 2) ? 2 : 1;        // fp/convolution.cpp:94-101
     const size_t row = (size_t) np * h->B;
     for (int r = 0; r < nrows; r++) {
-        float *dst = h->h_ir + r * row;
+        float *dst = stage + r * row;
         std::memcpy(dst, ir[r], sizeof(float) * (size_t) len);
         std::fill(dst + len, dst + row, 0.0f);
     }
     if (ir_channels == 2 && h->C == 1) {                              // tools::sumToMono, fp/tools.cpp:25-28
-        float *p0 = h->h_ir;
-        for (int i = 0; i < len; i++) { p0[i] += ir[1][i]; p0[i] /= 2.0f; }
+        for (int i = 0; i < len; i++) { stage[i] += ir[1][i]; stage[i] /= 2.0f; }
     }
     const int first_set = instance * h->C;
     if (np > 0) {
-        HIP_TRY(COPY_ASYNC(h, h->d_irtime, h->h_ir, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(COPY_ASYNC(h, h->d_irtime, stage, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
         int rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
         if (rc != IRB_OK) return rc;
     }
-    // the time-tiled kernel walks partitions in groups of kTT: rows up to the next multiple stay zero
-    const int np_pad = std::min((np + kTT - 1) / kTT * kTT, h->Ppad);
+    // the time-tiled kernels walk partitions in groups of kPadP: rows up to the next multiple stay zero
+    const int np_pad = std::min((np + kPadP - 1) / kPadP * kPadP, h->Ppad);
     for (int r = 0; r < nrows && np_pad > np; r++)
         HIP_TRY(hipMemsetAsync(h->d_H + ((size_t) (first_set + r) * h->Ppad + np) * h->M, 0,
                                sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
+    int2 *info = h->h_info_slot + (size_t) slot * h->C;
     for (int c = 0; c < h->C; c++) {
         h->h_set_of_stream[first_set + c] = first_set + (nrows == 2 ? c : 0);   // fp/convolution.cpp:176-181
         h->h_np_of_set[first_set + c] = np;
     }
-    int rc = upload_maps(h);
-    if (rc != IRB_OK) return rc;
-    HIP_TRY(irb_sync(h));
+    for (int c = 0; c < h->C; c++) info[c] = make_int2(h->h_set_of_stream[first_set + c], h->h_np_of_set[h->h_set_of_stream[first_set + c]]);
+    update_pairing(h);
+    HIP_TRY(COPY_ASYNC(h, h->d_stream_info + first_set, info, sizeof(int2) * h->C, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_ir[slot], h->stream));
+    h->ir_used[slot] = true;
+    h->ir_slot ^= 1;
     return IRB_OK;
 }
 
@@ -529,7 +575,17 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
     if (partition < 0 || partition >= h->P) return fail(IRB_ERR_ARG, "partition %d out of range [0,%d)", partition, h->P);
     HIP_TRY(hipSetDevice(h->device));
     const int first_set = instance * h->C;
-    // the staging slot of this partition: a call may be enqueued P times before anything is synchronised
+    // the staging slot of this partition: a call may be enqueued for P distinct partitions before anything is synchronised;
+    // a second refresh of the SAME partition slot (another instance, or the same one again) first waits for the stream,
+    // because the kernel enqueued earlier may not have read the slot yet
+    if (!h->part_busy) std::fill(h->part_slot_busy.begin(), h->part_slot_busy.end(), 0);
+    if (h->part_slot_busy[partition] || h->ir_used[0]) {
+        HIP_TRY(irb_sync(h));
+        std::fill(h->part_slot_busy.begin(), h->part_slot_busy.end(), 0);
+        h->ir_used[0] = false;                                       // whatever irb_fdl_set_ir staged in slot 0 has been consumed
+    }
+    h->part_slot_busy[partition] = 1;
+    h->part_busy = true;
     float *hs = h->h_ir + (size_t) partition * h->B;
     float *ds = h->d_irtime + (size_t) partition * h->B;
     std::memcpy(hs, samples, sizeof(float) * h->B);
@@ -578,7 +634,7 @@ int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra
         if (!spectra[r] && np > 0) return fail(IRB_ERR_ARG, "spectra[%d] is null", r);
         float2 *dst = h->d_H + (size_t) (first_set + r) * h->Ppad * h->M;
         if (np > 0) HIP_TRY(COPY_ASYNC(h, dst, spectra[r], sizeof(float2) * (size_t) np * h->M, hipMemcpyHostToDevice, h->stream));
-        const int np_pad = std::min((np + kTT - 1) / kTT * kTT, h->Ppad);
+        const int np_pad = std::min((np + kPadP - 1) / kPadP * kPadP, h->Ppad);
         if (np_pad > np) HIP_TRY(hipMemsetAsync(dst + (size_t) np * h->M, 0, sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
     }
     for (int c = 0; c < h->C; c++) {
@@ -722,6 +778,7 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
     // in mapped host memory (what the plug-in adapter creates)
     const bool one_launch = h->host_io && h->I == 1 && h->pair && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
                             !(h->flags & IRB_FDL_NO_RT_KERNEL);
+    if (h->ir_used[0]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[0])); h->ir_used[0] = false; }   // slot 0 of the IR staging is about to be rewritten
     if (one_launch) {
         for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s], sizeof(float) * n);
         for (int j = 0; j < n_blocks; j++) {
@@ -873,16 +930,16 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     const int need_T = (int) std::min<long>(steps, 4096);
-    irb_fdl *h = g_offline_engine;
+    irb_fdl *h = g_offline.eng;
     if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= need_T && h->Tmax <= 8 * need_T + 64)) {
-        if (h) { irb_fdl_destroy(h); g_offline_engine = nullptr; }
+        if (h) { irb_fdl_destroy(h); g_offline.eng = nullptr; }
         irb_fdl_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = P * B;
         cfg.max_blocks_per_call = need_T;
         int rc0 = irb_fdl_create(&cfg, &h);
         if (rc0 != IRB_OK) return rc0;
-        g_offline_engine = h;
+        g_offline.eng = h;
     }
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
@@ -1006,7 +1063,7 @@ int irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const
 
 void irb_fdl_release_cached_engine_(void)
 {
-    if (g_offline_engine) { irb_fdl_destroy(g_offline_engine); g_offline_engine = nullptr; }
+    if (g_offline.eng) { irb_fdl_destroy(g_offline.eng); g_offline.eng = nullptr; }
 }
 
 }  // extern "C"

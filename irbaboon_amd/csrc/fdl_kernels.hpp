@@ -64,6 +64,7 @@ struct StepArgs {
     int           rf_part;
     unsigned     *done;         // host-mapped word that receives done_seq after the last output store (nullptr: none)
     unsigned      done_seq;
+    int           debug_drop;   // test hook (IRB_DEBUG_DROP_GRANULES): the last workgroup of the grid withholds its granules in this launch
 };
 
 #ifdef IRB_STAMPS
@@ -900,6 +901,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         const float2 lo = b == 0 ? d : make_float2(t.x, t.y);       // packed bin 0: two real products
         const float2 hi = make_float2(t.z, t.w);
         if constexpr (HO == 2) {
+            if (a.debug_drop && blockIdx.x == gridDim.x - 1 && !(cs == 0 && ps == 0)) return;   // test hook: a producer that never publishes
             unsigned long long *g = a.gran + ((size_t) s * PS + ps) * (2 * M) + 2 * b;     // one granule per float
             const unsigned long long tag = (unsigned long long) a.epoch << 32;
             __hip_atomic_store(g + 0, tag | __float_as_uint(lo.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -956,7 +958,9 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
             if (f < 2 * M) yf[f] = v[i];
         }
         if (gave_up) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __syncthreads();
+        // a stream whose sum is incomplete writes neither output nor overlap: the host reports IRB_ERR_STATE for this step
+        // and the caller resets the handle (the ring slot of this block has been written, the overlap is one block stale)
+        if (__syncthreads_or(gave_up)) return;
         if (wave == 0) {
             wave_split_inverse<M>(l_buf, l_tw, lane);
             wave_fft<M, true>(l_buf, l_tw, lane);

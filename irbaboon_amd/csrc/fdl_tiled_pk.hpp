@@ -19,6 +19,10 @@ namespace irb {
 
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
+// H rows per IR set are a multiple of this (zero rows past the IR's partitions): one trip around the register ring of the
+// tile below (3 steps of 8 partitions), so a worker never needs a remainder loop
+constexpr int kTilePeriod = 24;
+
 // acc += x * h for one complex bin, as two packed FMAs:
 //   acc.xy += ( x.x, x.x) * (f.x, f.y)
 //   acc.xy += (-x.y, x.y) * (g.y, g.x)
@@ -79,38 +83,40 @@ __device__ __forceinline__ void tile_period(const float4 *__restrict__ H4, const
     }
 }
 
+// partitions [sb, se) of one worker; se - sb is a multiple of kTilePeriod (whole trips around the ring: every register
+// index is a constant and nothing ever moves between registers)
 template <int N, int TT, int U, bool NT, bool PACKED>
 __device__ __forceinline__ void tile_run(const float4 *__restrict__ H4, const float4 *__restrict__ X4, int col, int sb, int se, int j0,
                                          int head, int R, v2f_t (&acc)[TT][2], bool packed)
 {
     using G = MacGeom<N>;
     using TP = TilePk<TT, U>;
+    static_assert(kTilePeriod % (U * TP::PERIOD) == 0, "worker ranges are multiples of kTilePeriod partitions");
     float4 xr[TP::W];
-    int k0 = sb;
 #pragma unroll
     for (int i = U; i < TT + U - 1; i++)
-        xr[TP::phys(i, 0)] = ld16<NT>(X4 + (size_t) ring_slot(head, j0 - k0 - (U - 1) + i, R) * G::L + col);
-    // whole trips around the ring: every register index is a constant and nothing moves between registers
+        xr[TP::phys(i, 0)] = ld16<NT>(X4 + (size_t) ring_slot(head, j0 - sb - (U - 1) + i, R) * G::L + col);
 #pragma unroll 1
-    for (; k0 + U * TP::PERIOD <= se; k0 += U * TP::PERIOD)
+    for (int k0 = sb; k0 < se; k0 += U * TP::PERIOD)
         tile_period<N, TT, U, 0, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
-    // the last < PERIOD steps: step 0 again, the window moved down the ring by U registers after each
-#pragma unroll 1
-    for (; k0 < se; k0 += U) {
-        tile_step<N, TT, U, 0, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
-#pragma unroll
-        for (int i = TT + U - 2; i >= U; i--) xr[TP::phys(i, 0)] = xr[TP::phys(i - U, 0)];
-    }
 }
 
-// grid = S * ceil(T/TT) * splits, as k_cmac_tiled; partial spectra part[s][j][q][M], q = split * STRIPES + stripe.
-// H rows are zero padded to multiples of 8 by the host; U divides 8.
+// grid = S * ceil(T/TT) * splits, as k_cmac_tiled.  The stripes of a workgroup (partition sub-ranges of the same outputs)
+// are added through LDS before anything leaves the CU, so a workgroup writes ONE partial spectrum per output:
+// part[s][j][split][M] (round 2 wrote one per stripe: at one stream x 3750 blocks that was 61 MB of partials written,
+// flushed at the kernel boundary and read back by the inverse-FFT kernel -- more bytes than H and the FDL together).
+// H rows are zero padded to multiples of kTilePeriod by the host (and the allocation ends with spare rows for the last
+// read-ahead of a diagnostic build); a worker's partition range is a whole number of periods.
+// Tried and dropped (profiles/r03_tiled_stamps.txt): a 16 x 4 tile with the NEXT step's rows already in flight while the
+// current step is multiplied (window ring of TT + 2U - 1 rows, H double buffered, 255 VGPRs) -- same time within 1 %: the
+// loop is bound by how fast one or two waves per SIMD issue v_pk_fma_f32 (5.4-6.5 cycles each at the ~1.7 GHz the chip
+// holds under this load), not by the latency of its loads.
 template <int N, int TT, int U, int MINW, bool NT = false>
 __global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2;
-    static_assert(8 % U == 0, "U must divide the H row padding");
+    __shared__ float4 l_red[G::STRIPES > 1 ? G::STRIPES - 1 : 1][TT][G::LW];
     const int ntiles = (a.T + TT - 1) / TT;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
@@ -119,10 +125,17 @@ __global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
     const int col0 = threadIdx.x % G::LW;
     const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
     const int q = split * G::STRIPES + stripe;
-    const int nG = (np + 7) / 8 * (8 / U), nW = a.splits * G::STRIPES;
-    const int sb = (int) ((long) nG * q / nW) * U, se = (int) ((long) nG * (q + 1) / nW) * U;
+    const int nG = (np + kTilePeriod - 1) / kTilePeriod, nW = a.splits * G::STRIPES;
+    const int sb = (int) ((long) nG * q / nW) * kTilePeriod, se = (int) ((long) nG * (q + 1) / nW) * kTilePeriod;
     const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
     const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
+    IRB_STAMP(a, 0);
+#ifdef IRB_STAMPS
+    if (threadIdx.x == 0) {                            // where this workgroup runs: HW_ID (wave / SIMD / CU / SE) and the XCD
+        a.stamps[(size_t) blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, 32 bits
+        a.stamps[(size_t) blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID[3:0]
+    }
+#endif
 
 #pragma unroll 1
     for (int c = 0; c < G::CPT; c++) {
@@ -136,14 +149,36 @@ __global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
             if (wave_has_col0) tile_run<N, TT, U, NT, true>(H4, X4, col, sb, se, j0, a.head, a.R, acc, col == 0);
             else               tile_run<N, TT, U, NT, false>(H4, X4, col, sb, se, j0, a.head, a.R, acc, false);
         }
+        IRB_STAMP(a, 1);
+        if constexpr (G::STRIPES > 1) {
+            if (c > 0) __syncthreads();                // the previous column block's sums have been read
+            if (stripe > 0) {
 #pragma unroll
-        for (int j = 0; j < TT; j++) {
-            if (j0 + j < a.T) {
-                float4 *dst = reinterpret_cast<float4 *>(a.part + (((size_t) s * a.T + j0 + j) * a.nq + q) * M);
-                dst[col] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+                for (int j = 0; j < TT; j++) l_red[stripe - 1][j][col0] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+            }
+            __syncthreads();
+            if (stripe == 0) {
+#pragma unroll
+                for (int j = 0; j < TT; j++) {
+#pragma unroll
+                    for (int t = 0; t < G::STRIPES - 1; t++) {
+                        const float4 v = l_red[t][j][col0];
+                        acc[j][0].x += v.x; acc[j][0].y += v.y; acc[j][1].x += v.z; acc[j][1].y += v.w;
+                    }
+                }
+            }
+        }
+        if (stripe == 0) {
+#pragma unroll
+            for (int j = 0; j < TT; j++) {
+                if (j0 + j < a.T) {
+                    float4 *dst = reinterpret_cast<float4 *>(a.part + (((size_t) s * a.T + j0 + j) * a.nq + split) * M);
+                    dst[col] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+                }
             }
         }
     }
+    IRB_STAMP(a, 7);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -548,17 +548,16 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
 
 
-@pytest.mark.parametrize("kernel", ["1", "2", "3", "4"], ids=["pk16x8", "pk16x4", "pk12x4", "pk8x8"])
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 512, 6000, 16), (3, 1, 64, 900, 50),
                                         (1, 2, 1024, 9000, 17), (1, 1, 2048, 9000, 5)])
-def test_packed_fma_tiled_kernels(monkeypatch, kernel, I, C, B, Lh, T):
-    """k_cmac_tiled_pk (v_pk_fma_f32, register-ring window; IRB_TILED_KERNEL 1..4 = tile shapes 16x8 / 16x4 / 12x4 / 8x8)
+def test_packed_fma_tiled_kernel(monkeypatch, I, C, B, Lh, T):
+    """k_cmac_tiled_pk (v_pk_fma_f32, register-ring window, stripes added in LDS; the default, IRB_TILED_KERNEL=1)
     against round 2's k_cmac_tiled (IRB_TILED_KERNEL=0) and the oracle: calls that end inside a tile, partition
     counts that are not a multiple of the ring period, packed bin 0, one call split in two (FDL history across calls)."""
     x = _streams(I, C, T * B, 755)
     irs = [np.stack([decaying_ir(760 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
-    for k in (kernel, "0"):
+    for k in ("1", "0"):
         monkeypatch.setenv("IRB_TILED_KERNEL", k)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
@@ -780,6 +779,34 @@ def test_column_sliced_handoff_under_uneven_load():
         stop.set()
         th.join()
     assert max(res) < 2e-6, res
+
+
+def test_granule_handoff_timeout_is_reported_and_recoverable(monkeypatch):
+    """The tagged-granule hand-off of k_step_cols (the default for few streams, the plug-in's long-IR engines included) spins
+    on other workgroups' stores with a 50 ms bound.  IRB_DEBUG_DROP_GRANULES=3 makes one producer of the third launch
+    withhold its granules: that launch must END (no hang), the blocking call must report IRB_ERR_STATE exactly once, and
+    after irb_fdl_reset the handle must produce correct samples again."""
+    import time
+    B, Lh, T = 256, 96000, 6
+    x, h = white_noise(8100, T * B)[None], decaying_ir(8101, Lh)[None]
+    monkeypatch.setenv("IRB_DEBUG_DROP_GRANULES", "3")
+    monkeypatch.setenv("IRB_COLS_HANDOFF", "2")
+    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=1) as eng:
+        assert eng.info.splits > 1                                   # a multi-workgroup step: there is a hand-off to lose
+        eng.set_ir(0, h)
+        eng.process(x[:, :B])
+        eng.process(x[:, B:2 * B])
+        t0 = time.perf_counter()
+        with pytest.raises(_lib.IrbError) as e:
+            eng.process(x[:, 2 * B:3 * B])
+        dt = time.perf_counter() - t0
+        assert e.value.code == _lib.IRB_ERR_STATE and "hand-off timed out" in str(e.value)
+        assert 0.03 < dt < 2.0                                       # the bounded spin (50 ms), not a hang
+        eng.synchronize()                                            # reported once: the status word was consumed
+        eng.reset()
+        y = eng.process(x)
+    ref, _ = oracle.convolve_periodic(x, h, B)
+    assert rel_rms(y[0], ref[0, :T * B]) < RMS_TOL
 
 
 @pytest.mark.parametrize("ho", ["0", "2"])
