@@ -59,6 +59,7 @@ struct irb_fdl {
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
+    int fused_u = 2;                         // partitions per stripe whose rows a thread of k_step_fused keeps in flight (2 or 4)
     int colW = 0;                            // > 0: one-block steps use k_step_cols with slices of colW float4 columns,
                                              // `splits` then counts partition splits (workgroups per stream = CS * splits)
     int cols_handoff = 0;                    // its hand-off (k_step_cols HO): 0 write-through slices + ticket, 1 fences + ticket, 2 tagged granules
@@ -167,13 +168,14 @@ void choose_path(irb_fdl *h)
         return;
     }
     // Measured on MI355X (profiles/r02_latency_sweep.txt, r02_batch_sweep.txt, r02_step_stamps.txt):
-    //  * from 256 streams on, one workgroup per stream fills the chip and needs no hand-off: fused kernel;
+    //  * from 224 streams on, one workgroup per stream (nearly) fills the chip and needs no hand-off: fused kernel
+    //    (profiles/r03_batch_sweep.txt: 192 streams cols 1042 / fused 1002 Msamples/s, 256 streams cols 949 / fused 1060);
     //  * short IRs: the hand-off (~2 us: drained write-through store, ticket, slice loads) costs more than streaming
     //    the few rows in one workgroup (fused ~ 5.7 us + 0.05 us per 2-KiB partition row);
     //  * otherwise column slices x partition splits with <= 256 workgroups (a second workgroup per CU only queues
     //    behind the first on this latency-bound path), two rounds of loads per thread for long IRs (more splits
     //    shorten the loads but every workgroup adds ~13 ns to the stream's ticket counter and a row to the final sum).
-    if (!force_cols && (h->S >= env_int("IRB_FUSED_FROM", 256) || (long) h->P * h->N <= env_int("IRB_FUSED_ROWS", 48) * 512L)) return;
+    if (!force_cols && (h->S >= env_int("IRB_FUSED_FROM", 224) || (long) h->P * h->N <= env_int("IRB_FUSED_ROWS", 48) * 512L)) return;
     int W = 64;
     for (int w : {4, 16, 64}) {
         const int we = std::min(w, L);
@@ -273,6 +275,8 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
             if (h->nt) { FOR_N(h->N, irb::k_step_fused_pair<NN, true><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
             else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         }
+        else if (h->fused_u == 4 && h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 4, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else if (h->fused_u == 4)          { FOR_N(h->N, irb::k_step_fused<NN, 4, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
@@ -420,6 +424,10 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
     if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
     h->debug_drop_at = env_int("IRB_DEBUG_DROP_GRANULES", 0);
+    // at most one workgroup per CU (no second workgroup to overlap its loads with): twice the rows in flight per thread
+    // (profiles/r03_batch_sweep.txt: 256 streams 945 -> 1060 Msamples/s; as soon as some CUs hold two workgroups U = 2 is faster)
+    h->fused_u = env_int("IRB_FUSED_U", (h->colW == 0 && h->splits <= 1 && h->S <= 256) ? 4 : 2);
+    if (h->fused_u != 4) h->fused_u = 2;
     h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
     if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
     h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
