@@ -85,7 +85,10 @@ void irb_release_cached_plans(void);
  * on device buffers; buffers / synchronize / mark / elapsed_ms have no reference counterpart. */
 int  irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out);   /* fft_len: 2^5 .. 2^23 */
 void irb_lfft_destroy(irb_lfft *p);
-/* scratch owned by the plan (no reference counterpart): d_time [max_batch][N] floats, d_spec [max_batch][2N] floats */
+/* scratch owned by the plan (no reference counterpart): d_time [max_batch][N] floats, d_spec [max_batch][2N] floats.
+ * The plan zeroes d_spec once and a forward transform INTO d_spec then writes bins 0..N/2 only (the reference layout's
+ * zeros above the Nyquist bin are already there); a caller that stores into floats N+2 .. 2N-1 of d_spec itself must
+ * clear them again before the next forward transform into it.  Forward transforms into any other buffer write all 2N floats. */
 int  irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec);
 /* performRealOnlyForwardTransform / performRealOnlyInverseTransform (fp/tools.cpp:335,363) on device buffers */
 int  irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int batch);   /* asynchronous */

@@ -47,6 +47,9 @@ std::vector<float2> root_table(int root, int count, int stride)      // W_root^(
 
 }  // namespace
 
+struct SmoothWindows;
+void free_windows(SmoothWindows *w);
+
 struct irb_lfft {
     int device = 0, N = 0, M = 0, M1 = 0, M2 = 0, max_batch = 1, logE = 0;
     int tile_rows = 0;                           // four-step passes: rows/columns per workgroup (0 = one wave per item)
@@ -56,6 +59,14 @@ struct irb_lfft {
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tabA = nullptr, *d_tabB = nullptr;
     float2 *d_w0 = nullptr, *d_w1 = nullptr;     // complex work buffers [max_batch][M]
     float *d_time = nullptr, *d_spec = nullptr;  // [max_batch][N] samples, [max_batch][2N] spectrum (one-shot API)
+    bool spec_upper_zero = false;                // floats above the Nyquist bin of d_spec are zero (set at create, kept by every
+                                                 // kernel of this library: they write bins 0..N/2 only): forward into d_spec skips the fill
+    int log_m1 = 0;                              // IRB_LFFT_LOG_M1: log2 of the first factor (0 = balanced split)
+    // smoothing (averagingFilter) workspace, created by the first smoothing call on this plan: log amplitudes and window
+    // means live in MAPPED pinned host memory (the element-wise kernels write / read it directly), and the window bounds
+    // of the last (bins, Hz per bin, octave fraction) are kept
+    float *h_log = nullptr, *h_mean = nullptr, *d_hlog = nullptr, *d_hmean = nullptr;
+    SmoothWindows *win = nullptr;
 };
 
 namespace {
@@ -77,7 +88,7 @@ irb::LfftArgs args_of(const irb_lfft *p, int batch)
 {
     irb::LfftArgs a;
     a.tw1 = p->d_tw1; a.tw2 = p->d_tw2; a.tabA = p->d_tabA; a.tabB = p->d_tabB; a.logE = p->logE;
-    a.N = p->N; a.M = p->M; a.M1 = p->M1; a.M2 = p->M2; a.batch = batch; a.scale = 1.0f;
+    a.N = p->N; a.M = p->M; a.M1 = p->M1; a.M2 = p->M2; a.batch = batch; a.scale = 1.0f; a.zero_fill = 1;
     return a;
 }
 
@@ -238,6 +249,9 @@ void irb_lfft_destroy(irb_lfft *p)
     if (p->stream) (void) hipStreamSynchronize(p->stream);
     (void) hipFree(p->d_tw1); (void) hipFree(p->d_tw2); (void) hipFree(p->d_tabA); (void) hipFree(p->d_tabB);
     (void) hipFree(p->d_w0); (void) hipFree(p->d_w1); (void) hipFree(p->d_time); (void) hipFree(p->d_spec);
+    if (p->h_log) (void) hipHostFree(p->h_log);
+    if (p->h_mean) (void) hipHostFree(p->h_mean);
+    free_windows(p->win);
     for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
     if (p->stream) (void) hipStreamDestroy(p->stream);
     delete p;
@@ -259,7 +273,13 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
     p->device = device; p->N = fft_len; p->M = fft_len / 2; p->max_batch = max_batch;
     const int m = ilog2(p->M);
     if (p->M <= 2048) { p->M1 = p->M; p->M2 = 1; }
-    else { p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1; }
+    else {
+        p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1;
+        if (const char *v = std::getenv("IRB_LFFT_LOG_M1")) {            // tuning: another split of M = M1 * M2 (both factors 16..2048)
+            const int l1 = std::atoi(v);
+            if (l1 >= 4 && l1 <= 11 && m - l1 >= 4 && m - l1 <= 11) { p->M1 = 1 << l1; p->M2 = p->M / p->M1; }
+        }
+    }
     p->logE = std::min(10, ilog2(p->N));
     if (p->M2 > 1) {
         // rows / columns per workgroup: 8 gives 64-byte global pieces; a single 2^20 transform then has only 64-128
@@ -267,8 +287,9 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
         p->tile_rows = (long) max_batch * std::min(p->M1, p->M2) / 8 >= 256 ? 8 : 4;
         if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 4, 8, 16
         // fused split passes (2 launches per transform instead of 3) pay while the transform is launch-bound
-        // (profiles/r02_lfft_fuse_ab.txt): inverse up to 2^20 points, forward (16-byte scattered bin stores) up to 2^18
-        p->fuse_split = (p->N <= (1 << 20) ? 1 : 0) | (p->N <= (1 << 18) ? 2 : 0);
+        // (profiles/r02_lfft_fuse_ab.txt, r03_lfft_ab.txt): both directions up to 2^20 points (round 3: the forward pass takes its
+        // split twiddles from the row transform's LDS table and skips the zero fill of the plan's own spectrum buffer)
+        p->fuse_split = (p->N <= (1 << 20) ? 1 : 0) | (p->N <= (1 << 20) ? 2 : 0);
         if (const char *v = std::getenv("IRB_LFFT_FUSE_SPLIT")) p->fuse_split = std::atoi(v);
         if (p->tile_rows == 16 && std::max(p->M1, p->M2) > 1024) p->tile_rows = 8;
     }
@@ -296,6 +317,10 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
             (e = hipMemcpy(p->d_tabB, tB.data(), sizeof(float2) * tB.size(), hipMemcpyHostToDevice)) != hipSuccess) {
             rc = failf(IRB_ERR_HIP, "%s: %s", "plan allocation", hipGetErrorString(e)); break;
         }
+        if ((e = hipMemset(p->d_spec, 0, sizeof(float) * (size_t) max_batch * 2 * p->N)) != hipSuccess) {
+            rc = failf(IRB_ERR_HIP, "%s: %s", "plan buffers", hipGetErrorString(e)); break;
+        }
+        p->spec_upper_zero = true;
         rc = setup_tiles(p);
     } while (0);
     if (rc != IRB_OK) { irb_lfft_destroy(p); return rc; }
@@ -309,8 +334,10 @@ int irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int b
     if (!p || !d_in || !d_spec) return irb_set_error_(IRB_ERR_ARG, "null argument");
     if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
     HIP_TRY(hipSetDevice(p->device));
+    const bool fill = !(d_spec == p->d_spec && p->spec_upper_zero);  // 4 MB of zeros per 2^20-point item unless they are known to be there
     if (fused_split(p, true)) {                                     // columns pass, then rows pass + split in one launch
-        const irb::LfftArgs a = args_of(p, batch);
+        irb::LfftArgs a = args_of(p, batch);
+        a.zero_fill = fill;
         FOR_M(p->M1, { int rc = launch_tile<MM, false, true>(p, a, reinterpret_cast<const float2 *>(d_in), p->d_w0, batch * (p->M2 / p->tile_rows)); if (rc != IRB_OK) return rc; });
         FOR_M(p->M2, { int rc = launch_fused<MM, true>(p, a, p->d_w0, d_spec, batch * (p->M1 / p->tile_rows)); if (rc != IRB_OK) return rc; });
         HIP_TRY(hipGetLastError());
@@ -319,7 +346,9 @@ int irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int b
     int rc = complex_fft<false>(p, reinterpret_cast<const float2 *>(d_in), p->d_w0, p->d_w1, batch);
     if (rc != IRB_OK) return rc;
     const long work = (long) batch * (p->M / 2 + 1);
-    irb::k_rsplit_fwd<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(args_of(p, batch), p->d_w1, d_spec);
+    irb::LfftArgs as = args_of(p, batch);
+    as.zero_fill = fill;
+    irb::k_rsplit_fwd<<<dim3((unsigned) ((work + 255) / 256)), dim3(256), 0, p->stream>>>(as, p->d_w1, d_spec);
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
@@ -406,7 +435,9 @@ int irb_fft_inv_transform(int device, const float *in, int fft_size, float *out)
     irb_lfft *p = nullptr;
     int rc = cached_plan(device, N, 1, &p);
     if (rc != IRB_OK) return rc;
-    hipError_t e = hipMemcpyAsync(p->d_spec, in, sizeof(float) * fft_size, hipMemcpyHostToDevice, p->stream);
+    // only bins 0..N/2 are read by the inverse transform (performRealOnlyInverseTransform ignores the rest): copy just those,
+    // which also keeps the upper half of the plan's spectrum buffer at zero
+    hipError_t e = hipMemcpyAsync(p->d_spec, in, sizeof(float) * (size_t) (N + 2), hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, 1);
     if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_time, sizeof(float) * N, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
@@ -497,6 +528,15 @@ void restarted_mean(const float *v, int limit, const Windows &w, int nbins, floa
 
 }  // namespace smoothing
 
+// window bounds kept with a plan between smoothing calls (see smooth_on_device)
+struct SmoothWindows {
+    int nbins = 0;
+    double hz_per_bin = 0.0, octave_fraction = 0.0;
+    smoothing::Windows w;
+};
+
+void free_windows(SmoothWindows *w) { delete w; }
+
 extern "C" {
 
 // convolution::averagingFilter (fp/convolution.cpp:406-546), one channel, in place, HOST code.
@@ -540,28 +580,45 @@ void irb_shifteroo(float *buf, int n)                               // fp/ir.cpp
 // the order-sensitive float running sum on the host, on a spectrum that stays in device memory.  `passes`
 // repetitions (deconvolve uses 3).  Same operation order as irb_averaging_filter; the transcendental
 // functions are the device's, so results agree to rounding (1e-6), not bit for bit.
+// Per pass: k_smooth_log_ampl writes the log amplitudes straight into mapped pinned host memory, ONE stream wait, the
+// sequential sliding sum on the host (pinned in, pinned out), k_smooth_apply reads the means from the mapped buffer --
+// no copy commands and no staging through pageable memory (round 2: two copies through pageable vectors and two waits
+// per pass).  The window bounds (two divisions and two roundings in double per bin, ~1.5 ms at 2^19 bins) are computed
+// once per (bins, Hz per bin, octave fraction) and kept with the plan.
 static int smooth_on_device(irb_lfft *p, float *d_spec, int N, double octave_fraction, double sample_rate,
                             int passes, int include_phase, int include_amplitude)
 {
     const int nbins = N / 2 + 1;
-    const smoothing::Windows win = smoothing::octave_windows(nbins, (sample_rate / 2) / (double) (N / 2), octave_fraction);
+    const double hz_per_bin = (sample_rate / 2) / (double) (N / 2);
+    hipError_t e = hipSuccess;
+    if (!p->h_log) {
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&p->h_log), sizeof(float) * (size_t) (p->N / 2 + 1), hipHostMallocMapped)) != hipSuccess ||
+            (e = hipHostMalloc(reinterpret_cast<void **>(&p->h_mean), sizeof(float) * (size_t) (p->N / 2 + 1), hipHostMallocMapped)) != hipSuccess ||
+            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_hlog), p->h_log, 0)) != hipSuccess ||
+            (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_hmean), p->h_mean, 0)) != hipSuccess)
+            return failf(IRB_ERR_HIP, "%s: %s", "smoothing workspace", hipGetErrorString(e));
+    }
+    if (!p->win || p->win->nbins != nbins || p->win->hz_per_bin != hz_per_bin || p->win->octave_fraction != octave_fraction) {
+        free_windows(p->win);
+        p->win = new (std::nothrow) SmoothWindows;
+        if (!p->win) return irb_set_error_(IRB_ERR_ARG, "out of host memory");
+        p->win->nbins = nbins; p->win->hz_per_bin = hz_per_bin; p->win->octave_fraction = octave_fraction;
+        p->win->w = smoothing::octave_windows(nbins, hz_per_bin, octave_fraction);
+    }
+    const smoothing::Windows &win = p->win->w;
     const float pad = std::log(smoothing::kAmplFloor);              // bins above Nyquist count as amplitude 0 -> 1e-16
-    std::vector<float> log_ampl((size_t) nbins), mean((size_t) nbins);
-    float *d_log = reinterpret_cast<float *>(p->d_w0), *d_mean = reinterpret_cast<float *>(p->d_w1);   // work buffers are idle here
     for (int pass = 0; pass < passes; pass++) {
-        irb::k_smooth_log_ampl<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<const float2 *>(d_spec), d_log, nbins);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(log_ampl.data(), d_log, sizeof(float) * nbins, hipMemcpyDeviceToHost, p->stream);
+        irb::k_smooth_log_ampl<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<const float2 *>(d_spec), p->d_hlog, nbins);
+        e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
         if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (log amplitudes)", hipGetErrorString(e));
-        smoothing::sliding_mean(log_ampl.data(), nbins, N, pad, win, nbins, mean.data());     // the order-sensitive float history
-        e = hipMemcpyAsync(d_mean, mean.data(), sizeof(float) * nbins, hipMemcpyHostToDevice, p->stream);
-        if (e != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing (averages)", hipGetErrorString(e));
-        irb::k_smooth_apply<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(d_spec), d_mean, nbins, 1,
+        smoothing::sliding_mean(p->h_log, nbins, N, pad, win, nbins, p->h_mean);              // the order-sensitive float history
+        irb::k_smooth_apply<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(d_spec), p->d_hmean, nbins, 1,
                                                                                       include_phase, include_amplitude);
         if ((e = hipGetLastError()) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "k_smooth_apply", hipGetErrorString(e));
-        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return failf(IRB_ERR_HIP, "%s: %s", "smoothing", hipGetErrorString(e));
     }
+    // h_mean is rewritten by the next pass only after that pass's own wait, which is stream-ordered behind this apply kernel;
+    // the caller's next wait (download of the result) covers the last one
     return IRB_OK;
 }
 

@@ -24,6 +24,7 @@ struct LfftArgs {
     int           logE;           // E = 1 << logE
     int           N, M, M1, M2, batch;
     float         scale;          // applied by the last pass of an inverse transform (1/N), 1 otherwise
+    int           zero_fill;      // forward: write the zeros above the Nyquist bin (0: the caller's buffer is known to hold them)
 };
 
 __device__ __forceinline__ float2 big_twiddle(const LfftArgs &a, unsigned e)    // W_N^e, e < N
@@ -133,6 +134,19 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     constexpr int TPT = (MX + NT - 1) / NT;                  // twiddle entries per thread
     float2 twv[TPT], v[EPT];
     const float2 *twsrc = COLS ? a.tw1 : a.tw2;
+    // the inter-pass factor's table entries (columns pass) are asked for now, with everything else this thread loads: they
+    // are needed only after the column transform, and a load issued there is a round trip nothing overlaps
+    constexpr int KPL = MX >= kWave ? MX / kWave : 1;
+    float2 wa[COLS ? KPL : 1], wb[COLS ? KPL : 1];
+    if (COLS) {
+        const unsigned n2 = (unsigned) (i0 + wave);
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
+            wa[i] = a.tabA[e >> a.logE];
+            wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TPT; i++) twv[i] = twsrc[min((int) threadIdx.x + i * NT, MX - 1)];
 #pragma unroll
@@ -158,17 +172,7 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_tile(LfftArgs a, const float
     float2 *mine = tile + wave * LD;
     wave_fft<MX, INV>(mine, l_tw, lane);
     if (COLS) {
-        // inter-pass factor W_M^(n2*k1) = A[e / E] * B[e % E]: all table loads of this lane first (one memory
-        // latency instead of one per element), then the products
-        const unsigned n2 = (unsigned) (i0 + wave);
-        constexpr int KPL = MX >= kWave ? MX / kWave : 1;
-        float2 wa[KPL], wb[KPL];
-#pragma unroll
-        for (int i = 0; i < KPL; i++) {
-            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
-            wa[i] = a.tabA[e >> a.logE];
-            wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
-        }
+        // inter-pass factor W_M^(n2*k1) = A[e / E] * B[e % E] (loaded at the top of the kernel, see wa / wb)
 #pragma unroll
         for (int i = 0; i < KPL; i++) {
             const int k1 = lane + i * kWave;
@@ -223,7 +227,14 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_rows_split(LfftArgs a, const
     const float2 *src = in + b * M;
     float2 *X = reinterpret_cast<float2 *>(spec + b * 2 * a.N);
 
+    __shared__ float2 l_w1[R];                               // W_N^k1 of the tile's rows
     float2 twv[TPT], v[EPT];
+    float2 w1a = make_float2(1.f, 0.f), w1b = w1a;
+    if (threadIdx.x < R) {
+        const unsigned k1 = (unsigned) row_of(threadIdx.x);
+        w1a = a.tabA[k1 >> a.logE];
+        w1b = a.tabB[k1 & ((1u << a.logE) - 1u)];
+    }
 #pragma unroll
     for (int i = 0; i < TPT; i++) twv[i] = a.tw2[min((int) threadIdx.x + i * NT, MX - 1)];
 #pragma unroll
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_rows_split(LfftArgs a, const
         const int idx = min((int) threadIdx.x + i * NT, MX * R - 1);
         v[i] = src[(size_t) row_of(idx / MX) * MX + idx % MX];                       // T[k1*M2 + n2]: whole rows
     }
+    if (threadIdx.x < R) l_w1[threadIdx.x] = cmul(w1a, w1b);
 #pragma unroll
     for (int i = 0; i < TPT; i++) {
         const int idx = threadIdx.x + i * NT;
@@ -245,15 +257,9 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_rows_split(LfftArgs a, const
     wave_fft<MX, false>(tile + wave * LD, l_tw, lane);
     __syncthreads();
 
-    // split: thread -> (k2 = idx / R, slot r = idx % R); table loads of all its bins first
-    float2 wa[EPT], wb[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; i++) {
-        const int idx = min((int) threadIdx.x + i * NT, MX * R - 1);
-        const unsigned e = (unsigned) row_of(idx % R) + (unsigned) M1 * (unsigned) (idx / R);
-        wa[i] = a.tabA[e >> a.logE];
-        wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
-    }
+    // split: thread -> (k2 = idx / R, slot r = idx % R).  W_N^e with e = k1 + M1*k2 factors into W_N^k1 (one value per tile
+    // slot: R table look-ups per workgroup, issued at the top) times W_N^(M1*k2) = W_(2*M2)^k2 -- the row transform's own
+    // table, already in LDS.  (Round 2 fetched two table entries from global memory per output bin.)
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const int idx = threadIdx.x + i * NT;
@@ -270,15 +276,18 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_rows_split(LfftArgs a, const
             } else {
                 const float2 ev = make_float2(0.5f * (p.x + q.x), 0.5f * (p.y - q.y));      // (p + conj q)/2
                 const float2 od = make_float2(0.5f * (p.y + q.y), -0.5f * (p.x - q.x));     // (p - conj q)/(2i)
-                X[e] = cadd(ev, cmul(cmul(wa[i], wb[i]), od));
+                X[e] = cadd(ev, cmul(cmul(l_w1[r], l_tw[k2]), od));
             }
         }
     }
-    // zeros above the Nyquist bin (float2 indices M+1 .. N-1), shared over the workgroups of this item
-    const int per = (M - 1 + groups - 1) / groups;
-    for (int i = threadIdx.x; i < per; i += NT) {
-        const int z = g * per + i;
-        if (z < M - 1) X[M + 1 + z] = make_float2(0.f, 0.f);
+    if (a.zero_fill) {
+        // zeros above the Nyquist bin (float2 indices M+1 .. N-1), shared over the workgroups of this item; skipped for the
+        // plan's own spectrum buffer, whose upper half nothing ever writes after the plan zeroed it
+        const int per = (M - 1 + groups - 1) / groups;
+        for (int i = threadIdx.x; i < per; i += NT) {
+            const int z = g * per + i;
+            if (z < M - 1) X[M + 1 + z] = make_float2(0.f, 0.f);
+        }
     }
 }
 
@@ -303,6 +312,18 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, con
     float2 *dst = out + b * M;
 
     float2 twv[TPT];
+    // inter-pass factor of this wave's column (needed after the column transform): asked for at the top
+    constexpr int KPL = MX >= kWave ? MX / kWave : 1;
+    float2 wa2[KPL], wb2[KPL];
+    {
+        const unsigned n2 = (unsigned) (i0 + wave);
+#pragma unroll
+        for (int i = 0; i < KPL; i++) {
+            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
+            wa2[i] = a.tabA[e >> a.logE];
+            wb2[i] = a.tabB[e & ((1u << a.logE) - 1u)];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TPT; i++) twv[i] = a.tw1[min((int) threadIdx.x + i * NT, MX - 1)];
 #pragma unroll 1
@@ -345,21 +366,10 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, con
     __syncthreads();
     float2 *mine = tile + wave * LD;
     wave_fft<MX, true>(mine, l_tw, lane);
-    {
-        const unsigned n2 = (unsigned) (i0 + wave);
-        constexpr int KPL = MX >= kWave ? MX / kWave : 1;
-        float2 wa[KPL], wb[KPL];
 #pragma unroll
-        for (int i = 0; i < KPL; i++) {
-            const unsigned e = 2u * n2 * (unsigned) min(lane + i * kWave, MX - 1);
-            wa[i] = a.tabA[e >> a.logE];
-            wb[i] = a.tabB[e & ((1u << a.logE) - 1u)];
-        }
-#pragma unroll
-        for (int i = 0; i < KPL; i++) {
-            const int k1 = lane + i * kWave;
-            if (MX >= kWave || k1 < MX) mine[k1] = cmulc(mine[k1], cmul(wa[i], wb[i]));
-        }
+    for (int i = 0; i < KPL; i++) {
+        const int k1 = lane + i * kWave;
+        if (MX >= kWave || k1 < MX) mine[k1] = cmulc(mine[k1], cmul(wa2[i], wb2[i]));
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < MX * R; idx += NT) {              // T[k1*M2 + n2]
@@ -414,7 +424,8 @@ __global__ __launch_bounds__(256) void k_rsplit_fwd(LfftArgs a, const float2 *__
         if (b != M - b) X[M - b] = make_float2(e.x - t.x, t.y - e.y);
     }
     // clear the unused upper half (float indices N+2 .. 2N): bins M+1 .. N-1
-    for (long i = idx + M + 1 - bt * per; i < a.N; i += per) X[i] = make_float2(0.f, 0.f);
+    if (a.zero_fill)
+        for (long i = idx + M + 1 - bt * per; i < a.N; i += per) X[i] = make_float2(0.f, 0.f);
 }
 
 // inverse: spec (bins 0..M) -> Z with IFFT_M(Z)[n] = N*(y[2n] + i*y[2n+1])
