@@ -235,13 +235,13 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
         res[name] = ent
         e.close()
 
-    run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 10,
+    run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 200,
         "ONE mono stream, whole 960000-sample signal in one call (time-tiled MAC); cache-resident, compute-bound")
     run("configs[1]_x2048_8_blocks_per_call", 2048, 1, 256, 96000, 8, 10,
         "2048 instances, 8 blocks per call: H and FDL rows are read once per 8 outputs")
     run("configs[2]_stereo_10s_ir_streaming", 1, 2, 128, 480000, 1, 400,
         "stereo, B=128, P=3750, one block per call (split-P path, 14.6 MiB working set: Infinity-Cache resident)")
-    run("configs[2]_stereo_10s_ir_offline", 1, 2, 128, 480000, 2048, 5, "same IRs, 2048 blocks per call (time-tiled)")
+    run("configs[2]_stereo_10s_ir_offline", 1, 2, 128, 480000, 2048, 50, "same IRs, 2048 blocks per call (time-tiled)")
     run("configs[3]_1024_instances_b512_streaming", 1024, 1, 512, 96000, 1, 100,
         "1024 mono instances, B=512, P=188, one block per call: HBM-bound (1.5 GiB working set)")
     run("rt_layout_1024_stereo_instances_mono_ir", 1024, 2, 256, 96000, 1, 100,

@@ -24,6 +24,10 @@ int  irb_next_power_of_two(int x);
 /* Replaces: tools::fftTransform(buffer) (fp/tools.cpp:321-346): len host samples -> out[2N],
  * N = nextPowerOfTwo(len) (channel 0 only, as the reference copies, :328).  len >= 17. */
 int  irb_fft_transform(int device, const float *in, int len, float *out);
+/* Replaces: tools::fftTransform(buffer, formatAmplPhase = true) (fp/tools.cpp:321-346, the loop at :337-342): bins
+ * 0..N/2 of the same transform as (amplitude, phase) pairs -- tools::binAmpl / binPhase (fp/tools.cpp:222-231).  As in the
+ * reference the amplitude overwrites the real part before binPhase reads it, so the stored phase is atan2(im, amplitude). */
+int  irb_fft_transform_ampl_phase(int device, const float *in, int len, float *out);
 
 /* Replaces: tools::fftInvTransform(buffer) (fp/tools.cpp:351-369): in[fft_size = 2N] -> out[N]. */
 int  irb_fft_inv_transform(int device, const float *in, int fft_size, float *out);

@@ -79,6 +79,7 @@ SYMBOLS = [
     # include/irb_deconv.h
     ("irb_next_power_of_two", C.c_int, [C.c_int]),
     ("irb_fft_transform", C.c_int, [C.c_int, fp, C.c_int, fp]),
+    ("irb_fft_transform_ampl_phase", C.c_int, [C.c_int, fp, C.c_int, fp]),
     ("irb_fft_inv_transform", C.c_int, [C.c_int, fp, C.c_int, fp]),
     ("irb_averaging_filter", None, [fp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
     ("irb_shifteroo", None, [fp, C.c_int]),

@@ -409,8 +409,8 @@ int irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec)
     return IRB_OK;
 }
 
-// ---- tools::fftTransform (fp/tools.cpp:321-346, formatAmplPhase = false) -------------------------------
-int irb_fft_transform(int device, const float *in, int len, float *out)
+// ---- tools::fftTransform (fp/tools.cpp:321-346) ---------------------------------------------------------
+static int fft_transform_impl(int device, const float *in, int len, float *out, bool ampl_phase)
 {
     if (!in || !out || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
     const int N = std::max(32, irb_next_power_of_two(len));
@@ -421,11 +421,19 @@ int irb_fft_transform(int device, const float *in, int len, float *out)
     hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * N, p->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_time, in, sizeof(float) * len, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) { rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, 1); }
+    if (e == hipSuccess && rc == IRB_OK && ampl_phase) {            // :337-342, bins 0..N/2 (`bin <= N; bin += 2`)
+        const int nbins = N / 2 + 1;
+        irb::k_ampl_phase<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(reinterpret_cast<float2 *>(p->d_spec), nbins);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && rc == IRB_OK) e = hipMemcpyAsync(out, p->d_spec, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess && rc == IRB_OK) e = hipStreamSynchronize(p->stream);
     if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "irb_fft_transform", hipGetErrorString(e));
     return rc;
 }
+
+int irb_fft_transform(int device, const float *in, int len, float *out) { return fft_transform_impl(device, in, len, out, false); }
+int irb_fft_transform_ampl_phase(int device, const float *in, int len, float *out) { return fft_transform_impl(device, in, len, out, true); }
 
 // ---- tools::fftInvTransform (fp/tools.cpp:351-369): fft_size = 2N floats in, N samples out --------------
 int irb_fft_inv_transform(int device, const float *in, int fft_size, float *out)

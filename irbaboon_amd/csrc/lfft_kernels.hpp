@@ -505,6 +505,18 @@ __global__ __launch_bounds__(256) void k_smooth_apply(float2 *__restrict__ spec,
     spec[i] = make_float2(na * cosf(phase), na * sinf(phase));
 }
 
+// tools::fftTransform(buffer, formatAmplPhase = true), reference fp/tools.cpp:337-342: every bin 0..N/2 becomes
+// (binAmpl, binPhase).  The reference stores the amplitude into the real slot FIRST and only then calls binPhase on the same
+// two floats, so the phase it keeps is atan2(im, amplitude), not atan2(im, re): restated as written.
+__global__ __launch_bounds__(256) void k_ampl_phase(float2 *__restrict__ spec, int nbins)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    const double re = spec[i].x, im = spec[i].y;
+    const float ampl = (float) sqrt(re * re + im * im);       // binAmpl: sqrt(pow(re, 2.0) + pow(im, 2.0)) in double (fp/tools.cpp:222-225)
+    spec[i] = make_float2(ampl, atan2f(spec[i].y, ampl));     // binPhase on (amplitude, im) (fp/tools.cpp:228-231, :339-340)
+}
+
 // tools::complexMul over bins 0..N/2 (reference fp/convolution.cpp:326-331, fp/tools.cpp:44-52): a *= h
 __global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const float2 *__restrict__ h, int nbins)
 {

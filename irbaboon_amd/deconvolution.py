@@ -18,11 +18,13 @@ def nextPowerOfTwo(x):
     return _lib.lib().irb_next_power_of_two(int(x))
 
 
-def fftTransform(buffer, device=0):
-    """mono float32 samples -> 2N floats, interleaved (re, im) for bins 0..N/2, N = nextPowerOfTwo(len)."""
+def fftTransform(buffer, formatAmplPhase=False, device=0):
+    """mono float32 samples -> 2N floats, interleaved (re, im) for bins 0..N/2, N = nextPowerOfTwo(len);
+    formatAmplPhase=True: (amplitude, phase) pairs as the reference forms them (fp/tools.cpp:337-342)."""
     x = np.ascontiguousarray(buffer, np.float32).reshape(-1)
     out = np.zeros(2 * nextPowerOfTwo(x.size), np.float32)
-    check(_lib.lib().irb_fft_transform(device, _f(x), x.size, _f(out)))
+    fn = _lib.lib().irb_fft_transform_ampl_phase if formatAmplPhase else _lib.lib().irb_fft_transform
+    check(fn(device, _f(x), x.size, _f(out)))
     return out
 
 

@@ -356,6 +356,19 @@ int fp_fftTransform(const float *in, int len, float *out)
     return N;
 }
 
+/* fp/tools.cpp:321-346 with formatAmplPhase = true: the loop at :337-342 over `bin <= N; bin += 2`.  binAmpl (:222-225) is
+ * sqrt(pow(re, 2.0) + pow(im, 2.0)) in double, stored as float INTO THE REAL SLOT; binPhase (:228-231) then reads that slot:
+ * atan2(im, amplitude). */
+int fp_fftTransformAmplPhase(const float *in, int len, float *out)
+{
+    const int N = fp_fftTransform(in, len, out);
+    for (int bin = 0; bin <= N; bin += 2) {
+        out[bin] = (float) sqrt(pow((double) out[bin], 2.0) + pow((double) out[bin + 1], 2.0));
+        out[bin + 1] = (float) atan2((double) out[bin + 1], (double) out[bin]);
+    }
+    return N;
+}
+
 /* fp/tools.cpp:351-369 */
 void fp_fftInvTransform(const float *in, int fftSize, float *out)
 {

@@ -64,6 +64,8 @@ int fp_convolveNonPeriodic(const float *const *audio, int audio_ch, int La,
 int  fp_nextPowerOfTwo(int x);
 /* in: len samples; out: 2*N floats, N = nextPowerOfTwo(len); returns N */
 int  fp_fftTransform(const float *in, int len, float *out);
+/* the same with formatAmplPhase = true (fp/tools.cpp:337-342): (amplitude, atan2(im, amplitude)) per bin 0..N/2 */
+int  fp_fftTransformAmplPhase(const float *in, int len, float *out);
 /* in: 2*N floats (fftSize = 2N); out: N samples */
 void fp_fftInvTransform(const float *in, int fftSize, float *out);
 void fp_complexDivCartesian(float *a, float *b, float c, float d);

@@ -172,6 +172,8 @@ def _bind_cfg5():
     l.fp_nextPowerOfTwo.argtypes = [C.c_int]
     l.fp_fftTransform.restype = C.c_int
     l.fp_fftTransform.argtypes = [fp, C.c_int, fp]
+    l.fp_fftTransformAmplPhase.restype = C.c_int
+    l.fp_fftTransformAmplPhase.argtypes = [fp, C.c_int, fp]
     l.fp_fftInvTransform.argtypes = [fp, C.c_int, fp]
     l.fp_averagingFilter.argtypes = [fp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
     l.fp_deconvolve.restype = C.c_int
@@ -191,10 +193,10 @@ def next_pow2(x):
     return _bind_cfg5().fp_nextPowerOfTwo(int(x))
 
 
-def fft_transform(x):
+def fft_transform(x, ampl_phase=False):
     x = np.ascontiguousarray(x, np.float32)
     out = np.zeros(2 * next_pow2(x.size), np.float32)
-    _bind_cfg5().fp_fftTransform(_f(x), x.size, _f(out))
+    (_bind_cfg5().fp_fftTransformAmplPhase if ampl_phase else _bind_cfg5().fp_fftTransform)(_f(x), x.size, _f(out))
     return out
 
 

@@ -31,6 +31,22 @@ def test_fft_transform_matches_oracle_and_numpy(n):
     assert y.size == N and rel_rms(y[:n], x) < 1e-5 and (n == N or np.abs(y[n:]).max() < 1e-5)
 
 
+@pytest.mark.parametrize("n", [100, 4096, 1 << 16, 1 << 20])
+def test_fft_transform_ampl_phase_form(n):
+    """tools::fftTransform(buffer, formatAmplPhase=true), fp/tools.cpp:337-342: (amplitude, phase) per bin, with the
+    reference's quirk that the phase is taken AFTER the amplitude replaced the real part (atan2(im, amplitude))."""
+    x = white_noise(n + 3, n)
+    F, Fc = ib.fftTransform(x, formatAmplPhase=True), ib.fftTransform(x)
+    N = ib.nextPowerOfTwo(n)
+    O = oracle.fft_transform(x, ampl_phase=True)
+    assert rel_rms(F[0:N + 2:2], O[0:N + 2:2]) < 1e-5                       # amplitudes
+    assert np.abs(F[1:N + 2:2] - O[1:N + 2:2]).max() < 2e-3                 # phases in [-pi/2, pi/2]: |im| <= amplitude
+    amp = np.sqrt(Fc[0:N + 2:2].astype(np.float64) ** 2 + Fc[1:N + 2:2].astype(np.float64) ** 2)
+    assert np.allclose(F[0:N + 2:2], amp, rtol=1e-6, atol=1e-6)
+    assert np.allclose(F[1:N + 2:2], np.arctan2(Fc[1:N + 2:2].astype(np.float64), amp), atol=1e-6)
+    assert not F[N + 2:].any()
+
+
 def test_fft_transform_rejects_tiny_buffers():
     with pytest.raises(ib.IrbError):
         ib.fftTransform(np.ones(8, np.float32))

@@ -93,3 +93,17 @@ def test_invert_filter_roundtrip():
     inv = oracle.invert_filter(h, 48000)
     c = np.fft.irfft(np.fft.rfft(h.astype(np.float64)) * np.fft.rfft(inv.astype(np.float64)))
     assert abs(c[0]) > 0.8 and np.abs(c[1:]).max() < 0.35 * abs(c[0])
+
+
+def test_fft_transform_ampl_phase_quirk():
+    """fp/tools.cpp:337-342: the amplitude is written over the real part before binPhase reads the pair, so the oracle's
+    phase is atan2(im, amplitude) -- never outside [-pi/2, pi/2] -- not the bin's true phase."""
+    x = white_noise(77, 1000)
+    F, P = oracle.fft_transform(x), oracle.fft_transform(x, ampl_phase=True)
+    N = oracle.next_pow2(1000)
+    re, im = F[0:N + 2:2].astype(np.float64), F[1:N + 2:2].astype(np.float64)
+    amp = np.sqrt(re ** 2 + im ** 2)
+    assert np.allclose(P[0:N + 2:2], amp, rtol=1e-6)
+    assert np.allclose(P[1:N + 2:2], np.arctan2(im, amp), atol=1e-6)
+    assert np.abs(P[1:N + 2:2]).max() <= np.pi / 2 + 1e-6 and (re < 0).any()          # true phases would exceed pi/2 where re < 0
+    assert np.array_equal(P[N + 2:], F[N + 2:])                                        # the loop stops at bin N/2 (`bin <= N`)
