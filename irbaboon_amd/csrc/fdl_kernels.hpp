@@ -112,6 +112,12 @@ struct BlockIo {
             ov[i] = ovl[n];
         }
     }
+    // only the samples (a later block of the same launch: its overlap is already in `ov`, see overlap_add_keep)
+    __device__ __forceinline__ void load_x(const float *__restrict__ xin, int B, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < XL; i++) x[i] = xin[min(lane + i * kWave, B - 1)];
+    }
     // the block, zero padded to N reals, as the M-point complex input z[n] = x[2n] + i x[2n+1] (same memory)
     __device__ __forceinline__ void block_to_lds(float2 *buf, int B, int lane) const
     {
@@ -145,6 +151,21 @@ struct BlockIo {
 // acc += X[(head-k) mod R] * H[k].  Each lane: 16-byte loads of two complex bins from both rows.
 // dc accumulates the two real products of packed bin 0 (used by the lane that owns column 0).
 // ---------------------------------------------------------------------------------------------
+// the same, and the new overlap also stays in `ov` for the next block of this launch
+template <int N>
+__device__ __forceinline__ void overlap_add_keep(BlockIo<N> &io, const float2 *buf, int B, float *__restrict__ ovl, float *__restrict__ out, int lane)
+{
+    const float *y = reinterpret_cast<const float *>(buf);
+    const float scale = 1.0f / (float) N;
+#pragma unroll
+    for (int i = 0; i < BlockIo<N>::XL; i++) {
+        const int n = min(lane + i * kWave, B - 1);
+        const float o = y[n] * scale + io.ov[i], t = y[B + n] * scale;
+        io.ov[i] = t;
+        if (lane + i * kWave < B) { out[n] = o; ovl[n] = t; }
+    }
+}
+
 template <int N>
 struct MacGeom {
     static constexpr int M = N / 2;
@@ -218,8 +239,11 @@ __device__ __forceinline__ void mac_range(const float4 *__restrict__ H4, const f
     }
 }
 
+__device__ __forceinline__ void lds_barrier();     // defined below: workgroup barrier that waits for LDS traffic only
+
 // Combine the stripes of a workgroup: part is LDS [STRIPES][M]; result Y[M] (packed) in `Y`.
-template <int N>
+// LDS_ONLY: the two barriers do not drain the wave's global loads (k_rt_pair keeps the next block's samples in flight).
+template <int N, bool LDS_ONLY = false>
 __device__ __forceinline__ void reduce_stripes(const float4 (&acc)[MacGeom<N>::CPT], float2 dc, float2 *part, float2 *Y)
 {
     using G = MacGeom<N>;
@@ -233,14 +257,14 @@ __device__ __forceinline__ void reduce_stripes(const float4 (&acc)[MacGeom<N>::C
         part[stripe * G::M + b] = lo;
         part[stripe * G::M + b + 1] = make_float2(acc[c].z, acc[c].w);
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     for (int b = threadIdx.x; b < G::M; b += kThreads) {
         float2 s = part[b];
 #pragma unroll
         for (int t = 1; t < G::STRIPES; t++) s = cadd(s, part[t * G::M + b]);
         Y[b] = s;
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
 }
 
 template <int N>

@@ -45,13 +45,15 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
 
     stage_twiddles<N>(a.tw, lds.tw);                   // once for every block of the call (first barrier below covers it)
 
+    // samples of the first block + the saved overlaps (waves 0, 1), of the first IR partition (wave 2): they come from host
+    // memory, a PCIe round trip each.  Later blocks' samples are asked for one block ahead (below); the overlap stays in registers.
+    BlockIo<N> io;
+    if (wave < 2) io.load(a.in + (size_t) (s0 + wave) * a.in_stride, a.ovl + (size_t) (s0 + wave) * a.B, a.B, lane);
+    else if (wave == 2) io.load_x(a.rf_src + (size_t) (np > 0 ? a.rf_part % np : 0) * a.B, a.B, lane);
+
     for (int j = 0; j < a.T; j++) {
         const int head = (a.head + j) % a.R;
         const int rp = np > 0 ? (a.rf_part + j) % np : 0;
-        // small loads first: the new audio blocks + saved overlaps (waves 0, 1), the IR partition's samples (wave 2)
-        BlockIo<N> io;
-        if (wave < 2) io.load(a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) j * a.B, a.ovl + (size_t) (s0 + wave) * a.B, a.B, lane);
-        else if (wave == 2) io.load(a.rf_src + (size_t) rp * a.B, a.rf_src + (size_t) rp * a.B, a.B, lane);
         // rows that meet operands still in flight: H row 0 (partition 0 pairs with this block's spectra) and the FDL rows
         // the refreshed partition pairs with
         int slot_r = head - rp;
@@ -97,7 +99,12 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
         }
 
         if (wave < 3) io.block_to_lds(lds.buf[wave], a.B, lane);
-        __syncthreads();
+        if (j + 1 < a.T) {                             // the next block's samples land while this block is transformed
+            if (wave < 2) io.load_x(a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) (j + 1) * a.B, a.B, lane);
+            else if (wave == 2) io.load_x(a.rf_src + (size_t) (np > 0 ? (a.rf_part + j + 1) % np : 0) * a.B, a.B, lane);
+        }
+        // barriers inside a block order LDS traffic only (lds_barrier: no vmcnt drain), so those loads stay in flight
+        lds_barrier();
         if (wave < 2) {                                // new audio blocks: FFT, spectrum to LDS (partition 0) and into the ring
             wave_fft<M, false>(lds.buf[wave], lds.tw, lane);
             float2 *ring = Xs[wave] + (size_t) head * M;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
             float2 *row = Hs + (size_t) rp * M;
             wave_split_forward<M>(lds.buf[2], lds.tw, lane, [&](int b, float2 v) { lds.hnew[b] = v; row[b] = v; });
         }
-        __syncthreads();
+        lds_barrier();
         if (np > 0 && threadIdx.x < G::LW) {
 #pragma unroll
             for (int c = 0; c < G::CPT; c++) {
@@ -122,14 +129,14 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
                 }
             }
         }
-        __syncthreads();
-        reduce_stripes<N>(acc[0], dc[0], lds.scratch[0], lds.buf[0]);
-        reduce_stripes<N>(acc[1], dc[1], lds.scratch[1], lds.buf[1]);
+        lds_barrier();
+        reduce_stripes<N, true>(acc[0], dc[0], lds.scratch[0], lds.buf[0]);
+        reduce_stripes<N, true>(acc[1], dc[1], lds.scratch[1], lds.buf[1]);
         if (wave < 2) {
             wave_split_inverse<M>(lds.buf[wave], lds.tw, lane);
             wave_fft<M, true>(lds.buf[wave], lds.tw, lane);
-            io.overlap_add(lds.buf[wave], a.B, a.ovl + (size_t) (s0 + wave) * a.B,
-                           a.out + (size_t) (s0 + wave) * a.out_stride + (size_t) j * a.B, lane);
+            overlap_add_keep<N>(io, lds.buf[wave], a.B, a.ovl + (size_t) (s0 + wave) * a.B,
+                                a.out + (size_t) (s0 + wave) * a.out_stride + (size_t) j * a.B, lane);
         }
         // end of the block: its ring slot, H row and overlap are complete (every wave has drained its stores) before
         // the next block of this call reads them; one workgroup, one CU: a workgroup barrier is the whole hand-off

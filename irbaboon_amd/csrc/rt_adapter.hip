@@ -37,6 +37,7 @@ struct irb_rt {
     std::vector<float> outRing;               // [outSize][C][H] (:210)
     std::vector<const float *> inp;           // per-channel pointers handed to the engine (sized at create)
     std::vector<float *> outp;
+    std::vector<float *> sub;                 // channel pointers of a piece of an oversized host block
     int outSize = 0, outRd = 0, outWr = 0;
     std::vector<float> bypassRing;            // [outSize][C][H] (:211)
     int bypRd = 0, bypWr = 0;
@@ -70,6 +71,7 @@ int irb_rt_create(int device, int channels, int block, int ir_ring_len, irb_rt *
     p->inBlock.assign((size_t) channels * block, 0.0f);
     p->inp.assign((size_t) channels, nullptr);
     p->outp.assign((size_t) channels, nullptr);
+    p->sub.assign((size_t) channels, nullptr);
     *out = p;
     return IRB_OK;
 }
@@ -168,6 +170,18 @@ int irb_rt_process_block(irb_rt *p, float *const *buffer, int n)                
     if (n < 0) return irb_set_error_(IRB_ERR_ARG, "negative block length");
     const int C = p->C, B = p->B, H = p->H;
     for (int c = 0; c < C; c++) if (!buffer[c]) return irb_set_error_(IRB_ERR_ARG, "null channel pointer");
+    if (n > H) {
+        // a host that hands over more than the prepared block size (JUCE promises it never does): in pieces of at most H, so
+        // that the staging and the output ring sized by prepare_to_play always suffice (the reference would write its output
+        // ring past the slots it owns)
+        if (C > (int) p->sub.size()) return irb_set_error_(IRB_ERR_STATE, "adapter not prepared");
+        for (int off = 0; off < n; off += H) {
+            for (int c = 0; c < C; c++) p->sub[c] = buffer[c] + off;
+            int rc = irb_rt_process_block(p, p->sub.data(), std::min(H, n - off));
+            if (rc != IRB_OK) return rc;
+        }
+        return IRB_OK;
+    }
 
     // :421-445 collect host samples into blocks of B (run-wise copies; the reference moves one sample at a time)
     const size_t chan = (size_t) p->maxBlocks * B;          // per-channel pitch of ready / conv

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench.json, copied from a real MI355X run) keeps the driver's
+"""The committed bench line (profiles/r03_bench.json, copied from a real MI355X run) keeps the driver's
 contract: required keys, types, and internal consistency of the roofline / cpu_baseline objects."""
 import json
 import os
@@ -7,10 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_spot", "pcie_inclusive"):
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "n_gpus_visible", "steps", "warmup", "ms_per_step", "ms_per_step_wall", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_spot", "pcie_inclusive", "environment"):
         assert k in d, k
+    assert d["environment"]["library"].endswith("libirbfdl.so") and d["environment"]["irb_env"] == {}     # no tuning override behind the line
+    assert abs(d["ms_per_step"] - d["roofline"]["kernel_ms"]) < 1e-3 and 0.98 < d["ms_per_step_wall"] / d["ms_per_step"] < 1.05
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "Msamples/s"
     assert d["vs_baseline"] is None and base["published"] == {}            # nothing published to compare with
@@ -34,16 +36,34 @@ def test_committed_bench_line_follows_contract():
     assert "-march=native" in c["cflags"]
     chain = d["other_configs"]["configs[4]_2^20_deconvolve_chain"]
     assert chain["samples"] == 1 << 20 and chain["deconvolve_default_3x_smoothing_ms"] > chain["deconvolve_no_smoothing_ms"] > 0
+    # the two paths that had no number in the line
+    rt = d["other_configs"]["rt_processBlock"]
+    for hb, limit in ((256, 18.0), (512, 30.0)):
+        e = rt[f"host_block_{hb}"]
+        assert e["callbacks"] >= 2000 and 0 < e["median_us"] <= e["p99_us"] <= e["max_us"]
+        assert e["median_us"] <= limit                                     # VERDICT r2 item 2's targets
+        assert e["launches_per_callback"] == 1.0 and e["waits_per_callback"] == 1.0 and e["copies_per_callback"] == 0.0
+    for name, e in d["other_configs"].items():
+        if not isinstance(e, dict) or "blocks_per_call" not in e:
+            continue
+        if e["blocks_per_call"] == 1:                                      # streaming: bytes against the HBM peak
+            assert "algorithmic_GBps" in e and 0 < e["frac_of_hbm_peak"] < 1.0 and "fp32_flops" not in e
+        else:                                                              # time-tiled: flops against the fp32 vector peak, no GB/s figure
+            assert "algorithmic_GBps" not in e and "algorithmic_GBps_streaming_model" not in e
+            assert abs(e["TFLOPs"] - e["fp32_flops"] / (e["ms_per_call"] * 1e-3) / 1e12) / e["TFLOPs"] < 2e-2
+            assert abs(e["frac_of_157.3"] - e["TFLOPs"] / 157.3) < 1e-3 and e["frac_of_157.3"] < 1.0
 
 
 def test_every_bench_kernel_is_launched_by_a_parity_test():
-    """profiles/r02_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
-    (profiles/collect_r02.py): no kernel is timed that the parity suite does not also run."""
-    lines = open(os.path.join(ROOT, "profiles", "r02_kernel_coverage.txt")).read().strip().splitlines()
+    """profiles/r03_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
+    (profiles/collect_r03.py): no kernel is timed that the parity suite does not also run."""
+    lines = open(os.path.join(ROOT, "profiles", "r03_kernel_coverage.txt")).read().strip().splitlines()
     assert lines[-1] == "bench kernels without a parity-test launch: 0"
     rows = [l for l in lines[1:-1] if "irb::" in l]
     assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
     assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, 2" in l for l in rows)
+    assert any("k_rt_pair<512>" in l for l in rows) and any("k_cmac_tiled_pk<512, 16, 8, 2, false>" in l for l in rows)
+    assert any("k_ifft_ola_run<512, 4>" in l for l in rows) and any("k_lfft_rows_split<1024, 4>" in l for l in rows)
 
 
 def test_launch_mode_never_needs_a_prestarted_world():
