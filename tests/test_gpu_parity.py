@@ -224,6 +224,45 @@ def test_process_refresh_on_engine_shapes_without_the_rt_kernel(case):
     assert np.array_equal(ya, yb) and np.abs(ya[(I - 1) * C:]).max() > 0
 
 
+@pytest.mark.parametrize("B,P,nb,first", [(64, 5, 3, 2), (128, 8, 2, 0), (256, 3, 4, 1), (512, 6, 2, 5), (32, 9, 1, 4)],
+                         ids=lambda v: str(v))
+def test_rt_kernel_block_sizes_against_float64_model(B, P, nb, first):
+    """k_rt_pair<N> for N = 64 ... 1024 (the plug-in adapter only ever builds N = 512): one stereo instance, calls of nb blocks,
+    partition (first + j) mod P re-derived before block j -- against a float64 model written from the definition: block t sees
+    exactly the partitions refreshed so far, y_t = sum_k x_(t-k) * h_k over those k (Source/PluginProcessor.cpp:455-501).
+    The same calls through the refresh + step launches (IRB_FDL_NO_RT_KERNEL) must agree to rounding."""
+    n_calls = 2 * P // nb + 3
+    T = n_calls * nb
+    x = _streams(1, 2, T * B, 9400)
+    h = decaying_ir(9450, P * B)
+    outs = []
+    for extra in (0, _lib.NO_RT_KERNEL):
+        with FdlEngine(1, 2, B, P * B, max_blocks_per_call=nb, flags=_lib.HOST_IO | _lib.STEPWISE | extra) as eng:
+            part, ys = first, []
+            for k in range(n_calls):
+                ys.append(eng.process_refresh(x[:, k * nb * B:(k + 1) * nb * B], h, part))
+                part = (part + nb) % P
+            outs.append(np.concatenate(ys, axis=1))
+            launches = eng.counters()[0]
+        assert launches <= n_calls + 2 if extra == 0 else launches >= 2 * T
+    assert rel_rms(outs[0], outs[1]) < 2e-6
+    # float64 model: partition k is usable from the block at which it was first refreshed
+    avail_from = {}
+    for t in range(T):
+        avail_from.setdefault((first + t) % P, t)
+    ref = np.zeros((2, (T + 1) * B))
+    hk = [h[k * B:(k + 1) * B].astype(np.float64) for k in range(P)]
+    for c in range(2):
+        xc = x[c].astype(np.float64)
+        for t in range(T):
+            for k in range(P):
+                if k in avail_from and avail_from[k] <= t and t - k >= 0:
+                    seg = np.convolve(xc[(t - k) * B:(t - k + 1) * B], hk[k])          # 2B-1 samples starting at block t
+                    ref[c, t * B:t * B + 2 * B - 1] += seg
+    for c in range(2):
+        assert rel_rms(outs[0][c], ref[c, :T * B]) < RMS_TOL
+
+
 def test_rt_adapter_host_block_larger_than_block_is_causal():
     """hostBlock 512 > 256: the reference's FDL ring is one slot short and feeds a future block to
     its last partition; the adapter keeps P past blocks, so it must equal the true
