@@ -7,6 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "examples", "batch_convolve")
+EXE_RT = os.path.join(ROOT, "examples", "rt_callback")
 
 
 def test_headers_compile_as_c11(tmp_path):
@@ -18,9 +19,10 @@ def test_headers_compile_as_c11(tmp_path):
 
 def _build(hip_lib):
     so_dir = os.path.join(ROOT, "irbaboon_amd")
-    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "batch_convolve.c"), "-o", EXE,
-                           "-L" + so_dir, "-l:libirbfdl.so", "-Wl,-rpath," + so_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    for src, exe in (("batch_convolve.c", EXE), ("rt_callback.c", EXE_RT)):
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", src), "-o", exe,
+                               "-L" + so_dir, "-l:libirbfdl.so", "-Wl,-rpath," + so_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
 
 
 def test_c_example_builds(hip_lib):
@@ -33,3 +35,14 @@ def test_c_example_runs_on_gpu(hip_lib):
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "delta-delay max err" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_rt_example_runs_on_gpu(hip_lib):
+    """the plug-in callback driven from plain C: delta IR = pure delay of latency + 100 samples at host blocks 256 and 512,
+    and every callback is one launch and one wait"""
+    _build(hip_lib)
+    r = subprocess.run([EXE_RT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("host block")]
+    assert len(lines) == 2 and all("1.00 launches, 1.00 waits, 0.00 copies" in l for l in lines), r.stdout

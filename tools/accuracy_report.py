@@ -1,5 +1,5 @@
 """Measured relative RMS error of the GPU path per BASELINE configuration, against float64 FFT convolution
-(scipy) and, where it finishes in seconds, the CPU oracle.  Writes profiles/r01_accuracy.txt when run on the box."""
+(scipy) and, where it finishes in seconds, the CPU oracle.  Writes gpurun_out/accuracy.txt when run on the box (committed as profiles/rNN_accuracy.txt)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
