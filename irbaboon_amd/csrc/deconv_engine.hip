@@ -61,7 +61,6 @@ struct irb_lfft {
     float *d_time = nullptr, *d_spec = nullptr;  // [max_batch][N] samples, [max_batch][2N] spectrum (one-shot API)
     bool spec_upper_zero = false;                // floats above the Nyquist bin of d_spec are zero (set at create, kept by every
                                                  // kernel of this library: they write bins 0..N/2 only): forward into d_spec skips the fill
-    int log_m1 = 0;                              // IRB_LFFT_LOG_M1: log2 of the first factor (0 = balanced split)
     // smoothing (averagingFilter) workspace, created by the first smoothing call on this plan: log amplitudes and window
     // means live in MAPPED pinned host memory (the element-wise kernels write / read it directly), and the window bounds
     // of the last (bins, Hz per bin, octave fraction) are kept

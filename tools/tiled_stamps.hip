@@ -3,7 +3,7 @@
 // Answers "where do the microseconds between the waves' own work and the kernel's duration go" (launch ramp, rounds,
 // stragglers, tail).  Not part of libirbfdl.so.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DIRB_STAMPS -o tools/tiled_stamps tools/tiled_stamps.hip
-//   tools/tiled_stamps T splits [variant 1|2]
+//   tools/tiled_stamps T splits
 #define IRB_STAMPS 1
 #include "../irbaboon_amd/csrc/fdl_kernels.hpp"
 
@@ -18,7 +18,7 @@
 
 int main(int argc, char **argv)
 {
-    const int T = argc > 1 ? std::atoi(argv[1]) : 3750, splits = argc > 2 ? std::atoi(argv[2]) : 2, variant = argc > 3 ? std::atoi(argv[3]) : 1;
+    const int T = argc > 1 ? std::atoi(argv[1]) : 3750, splits = argc > 2 ? std::atoi(argv[2]) : 2;
     constexpr int N = 512, M = N / 2, B = 256, P = 375, TT = 16;
     const int Ppad = 384, R = Ppad + T + 8, ntiles = (T + TT - 1) / TT, grid = ntiles * splits;
     float2 *dH, *dX, *dpart;
@@ -79,7 +79,7 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < v.size(); i++) for (size_t j = i + 1; j < v.size(); j++)
             if (std::min(v[i].second, v[j].second) - std::max(v[i].first, v[j].first) > 0.5 * std::min(v[i].second - v[i].first, v[j].second - v[j].first)) overlap2++;
     }
-    std::printf("T=%d splits=%d variant=%d grid=%d: event time %.1f us; first start -> last end %.1f us (100 MHz clock)\n", T, splits, variant, grid, ms * 1e3, (t1 - t0) / 100.0);
+    std::printf("T=%d splits=%d grid=%d: event time %.1f us; first start -> last end %.1f us (100 MHz clock)\n", T, splits, grid, ms * 1e3, (t1 - t0) / 100.0);
     std::printf("  workgroup start (us after the first): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", pct(start, .1), pct(start, .5), pct(start, .9), pct(start, 1));
     std::printf("  workgroup duration (us):               p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", pct(dur, .1), pct(dur, .5), pct(dur, .9), pct(dur, 1));
     std::printf("  partition loop (shader cycles):        p10 %.0f  p50 %.0f  p90 %.0f  max %.0f\n", pct(loop, .1), pct(loop, .5), pct(loop, .9), pct(loop, 1));
