@@ -66,6 +66,9 @@ struct irb_fdl {
     unsigned long long *d_gran = nullptr;    // [S][splits][N] granules of hand-off form 2
     unsigned *h_status = nullptr, *d_status = nullptr;   // host-mapped word a kernel raises when a bounded spin gives up
     unsigned *h_done = nullptr, *d_done = nullptr;       // host-mapped completion word of the one-launch real-time callback (k_rt_pair)
+    float *bar_in = nullptr, *bar_ir = nullptr;          // IRB_FDL_HOST_IO on a large-BAR system: fine-grained DEVICE memory the audio thread stores its
+                                                         // blocks [S][Tmax*B] and IR partitions [P*B] into directly (posted writes over PCIe), so that
+                                                         // k_rt_pair's first loads are local instead of PCIe round trips (tools/bar_probe.hip: -2 us per callback)
     unsigned done_seq = 0;
     bool stepwise = false;                   // IRB_FDL_STEPWISE: a call of n blocks = n one-block steps, ring of P slots
     long long cols_launches = 0, debug_drop_at = 0;   // IRB_DEBUG_DROP_GRANULES=n (tests): the n-th column-sliced launch loses one producer's granules
@@ -258,6 +261,19 @@ int check_status(irb_fdl *h)
     if (h->h_status && *h->h_status) {
         *h->h_status = 0;
         *h->h_done = 0;
+        if (h->host_io && env_int("IRB_RT_BAR", 1)) {
+            int large_bar = 0;
+            if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
+                const size_t nin = (size_t) h->S * h->Tmax * h->B, nir = (size_t) h->P * h->B;
+                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir), hipDeviceMallocFinegrained) == hipSuccess) {
+                    h->bar_ir = h->bar_in + nin;
+                    h->bytes += sizeof(float) * (nin + nir);
+                } else {
+                    (void) hipGetLastError();                    // no such memory here: the pinned staging serves
+                    h->bar_in = nullptr;
+                }
+            }
+        }
         h->part_slot_busy.assign((size_t) h->P, 0);
         return fail(IRB_ERR_STATE, "in-kernel hand-off timed out (a producer workgroup never published its slice)");
     }
@@ -381,6 +397,7 @@ void irb_fdl_destroy(irb_fdl *h)
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
     if (h->h_status) (void) hipHostFree(h->h_status);
     if (h->h_done) (void) hipHostFree(h->h_done);
+    if (h->bar_in) (void) hipFree(h->bar_in);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_info_slot) (void) hipHostFree(h->h_info_slot);
@@ -486,6 +503,19 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         }
         *h->h_status = 0;
         *h->h_done = 0;
+        if (h->host_io && env_int("IRB_RT_BAR", 1)) {
+            int large_bar = 0;
+            if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
+                const size_t nin = (size_t) h->S * h->Tmax * h->B, nir = (size_t) h->P * h->B;
+                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir), hipDeviceMallocFinegrained) == hipSuccess) {
+                    h->bar_ir = h->bar_in + nin;
+                    h->bytes += sizeof(float) * (nin + nir);
+                } else {
+                    (void) hipGetLastError();                    // no such memory here: the pinned staging serves
+                    h->bar_in = nullptr;
+                }
+            }
+        }
         h->part_slot_busy.assign((size_t) h->P, 0);
         // twiddles: W_N^j in double, rounded to float
         std::vector<float2> tw(h->N);
@@ -788,13 +818,18 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
                             !(h->flags & IRB_FDL_NO_RT_KERNEL);
     if (h->ir_used[0]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[0])); h->ir_used[0] = false; }   // slot 0 of the IR staging is about to be rewritten
     if (one_launch) {
-        for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s], sizeof(float) * n);
+        // blocks and IR partitions: stored by this thread straight into device memory where the BAR allows it (write-only,
+        // write-combined; the fence below drains the combining buffers before the launch's doorbell), else left in mapped
+        // pinned host memory for the kernel to fetch
+        float *in_stage = h->bar_in ? h->bar_in : h->h_io, *ir_stage = h->bar_in ? h->bar_ir : h->h_ir;
+        for (int s = 0; s < h->S; s++) std::memcpy(in_stage + (size_t) s * stride, in[s], sizeof(float) * n);
         for (int j = 0; j < n_blocks; j++) {
             const int p = (first_partition + j) % h->P;
-            std::memcpy(h->h_ir + (size_t) p * h->B, ir + (size_t) p * h->B, sizeof(float) * h->B);
+            std::memcpy(ir_stage + (size_t) p * h->B, ir + (size_t) p * h->B, sizeof(float) * h->B);
         }
-        irb::StepArgs a = step_args(h, h->d_hio, h->d_hio + (size_t) h->S * stride, stride);
-        a.T = n_blocks; a.rf_src = h->d_hir; a.rf_part = first_partition;
+        if (h->bar_in) __builtin_ia32_sfence();
+        irb::StepArgs a = step_args(h, h->bar_in ? h->bar_in : h->d_hio, h->d_hio + (size_t) h->S * stride, stride);
+        a.T = n_blocks; a.rf_src = h->bar_in ? h->bar_ir : h->d_hir; a.rf_part = first_partition;
         a.done = h->d_done; a.done_seq = ++h->done_seq;
         if (a.done_seq == 0) a.done_seq = ++h->done_seq;            // 0 is the word's initial value
         h->n_launches++;
