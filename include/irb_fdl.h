@@ -51,6 +51,10 @@ extern "C" {
 #define IRB_FDL_STEPWISE      0x40u /* a call of n <= max_blocks_per_call blocks runs n one-block steps, never the time-tiled
                                        kernels; the FDL ring then holds exactly P slots (the real-time adapter's engine)   */
 #define IRB_FDL_NO_RT_KERNEL  0x80u /* irb_fdl_process_refresh: always the refresh launch + step launch per block (A/B, tests) */
+#define IRB_FDL_RESIDENT      0x100u /* irb_fdl_process_refresh (single stereo instance, IRB_FDL_HOST_IO, large-BAR system): requests are served by
+                                        a workgroup that stays resident on the GPU between callbacks (no kernel launch per callback); it exits
+                                        by itself after 20 ms without a request (the next callback starts a new one), after 10 s at the
+                                        latest, and whenever any other entry point of the handle is called                        */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */

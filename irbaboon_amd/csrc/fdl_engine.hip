@@ -66,6 +66,11 @@ struct irb_fdl {
     unsigned long long *d_gran = nullptr;    // [S][splits][N] granules of hand-off form 2
     unsigned *h_status = nullptr, *d_status = nullptr;   // host-mapped word a kernel raises when a bounded spin gives up
     unsigned *h_done = nullptr, *d_done = nullptr;       // host-mapped completion word of the one-launch real-time callback (k_rt_pair)
+    // IRB_FDL_RESIDENT: the real-time callback served by a resident workgroup (k_rt_server) instead of a launch per callback
+    bool resident = false, server_live = false;
+    irb::RtMailbox *bar_mb = nullptr;                    // request mailbox, in the BAR-mapped allocation below
+    hipStream_t rt_stream = nullptr;                     // the server's own stream: nothing else is ever enqueued behind it
+    unsigned server_gen = 0, idle_ticks = 0, life_ticks = 0;   // generation of the running server; its timeouts (100 MHz ticks)
     float *bar_in = nullptr, *bar_ir = nullptr;          // IRB_FDL_HOST_IO on a large-BAR system: fine-grained DEVICE memory the audio thread stores its
                                                          // blocks [S][Tmax*B] and IR partitions [P*B] into directly (posted writes over PCIe), so that
                                                          // k_rt_pair's first loads are local instead of PCIe round trips (tools/bar_probe.hip: -2 us per callback)
@@ -264,10 +269,18 @@ int check_status(irb_fdl *h)
         if (h->host_io && env_int("IRB_RT_BAR", 1)) {
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
-                const size_t nin = (size_t) h->S * h->Tmax * h->B, nir = (size_t) h->P * h->B;
-                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir), hipDeviceMallocFinegrained) == hipSuccess) {
+                const size_t nin = ((size_t) h->S * h->Tmax * h->B + 15) / 16 * 16, nir = ((size_t) h->P * h->B + 15) / 16 * 16;
+                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
                     h->bar_ir = h->bar_in + nin;
-                    h->bytes += sizeof(float) * (nin + nir);
+                    h->bar_mb = reinterpret_cast<irb::RtMailbox *>(h->bar_ir + nir);
+                    h->bytes += sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox);
+                    std::memset(h->bar_mb, 0, sizeof(irb::RtMailbox));          // through the BAR, like everything the host puts there
+                    __builtin_ia32_sfence();
+                    if ((h->flags & IRB_FDL_RESIDENT) && hipStreamCreateWithFlags(&h->rt_stream, hipStreamNonBlocking) == hipSuccess) {
+                        h->resident = true;
+                        h->idle_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_IDLE_US", 20000)) * 100u;
+                        h->life_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_LIFE_MS", 10000)) * 100000u;
+                    }
                 } else {
                     (void) hipGetLastError();                    // no such memory here: the pinned staging serves
                     h->bar_in = nullptr;
@@ -358,6 +371,42 @@ void update_pairing(irb_fdl *h)
     for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
 }
 
+// ---- resident real-time server (k_rt_server) --------------------------------------------------------------------------
+// the generation word the server stores last lives next to the completion word (h_done[1])
+inline volatile unsigned *exited_word(irb_fdl *h) { return h->h_done + 1; }
+
+int server_launch(irb_fdl *h, unsigned first_seq)
+{
+    // everything enqueued on the handle's own stream (IR tables, stream_info) must be in place before the server reads it
+    HIP_TRY(irb_sync(h));
+    irb::StepArgs a = step_args(h, h->bar_in, h->d_hio + (size_t) h->S * h->Tmax * h->B, (long) h->Tmax * h->B);
+    a.rf_src = h->bar_ir; a.done = h->d_done;
+    if (++h->server_gen == 0) ++h->server_gen;           // 0 is the exited word's initial value
+    h->n_launches++;
+    FOR_N_RT(h->N, irb::k_rt_server<NN><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->rt_stream>>>(
+                       a, h->bar_mb, h->d_done + 1, h->server_gen, first_seq, h->idle_ticks, h->life_ticks));
+    HIP_TRY(hipGetLastError());
+    h->server_live = true;
+    return IRB_OK;
+}
+
+// every entry point other than the real-time callback stops the server first: it owns the engine's state while it runs
+int server_stop(irb_fdl *h)
+{
+    if (!h->server_live) return IRB_OK;
+    h->bar_mb->quit = 1;
+    __builtin_ia32_sfence();
+    h->n_waits++;
+    hipError_t e = hipStreamSynchronize(h->rt_stream);   // at the latest the idle timeout ends it
+    h->bar_mb->quit = 0;
+    __builtin_ia32_sfence();
+    h->server_live = false;
+    if (e != hipSuccess) return fail(IRB_ERR_HIP, "real-time server: %s", hipGetErrorString(e));
+    return IRB_OK;
+}
+
+#define STOP_SERVER(h_) do { if ((h_)->server_live) { int rc_ = server_stop(h_); if (rc_ != IRB_OK) return rc_; } } while (0)
+
 int upload_maps(irb_fdl *h)
 {
     update_pairing(h);
@@ -391,6 +440,7 @@ void irb_fdl_destroy(irb_fdl *h)
 {
     if (!h) return;
     (void) hipSetDevice(h->device);
+    (void) server_stop(h);
     if (h->stream) (void) irb_sync(h);
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
@@ -398,6 +448,7 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->h_status) (void) hipHostFree(h->h_status);
     if (h->h_done) (void) hipHostFree(h->h_done);
     if (h->bar_in) (void) hipFree(h->bar_in);
+    if (h->rt_stream) (void) hipStreamDestroy(h->rt_stream);
     if (h->h_io) (void) hipHostFree(h->h_io);
     if (h->h_ir) (void) hipHostFree(h->h_ir);
     if (h->h_info_slot) (void) hipHostFree(h->h_info_slot);
@@ -506,10 +557,18 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (h->host_io && env_int("IRB_RT_BAR", 1)) {
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
-                const size_t nin = (size_t) h->S * h->Tmax * h->B, nir = (size_t) h->P * h->B;
-                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir), hipDeviceMallocFinegrained) == hipSuccess) {
+                const size_t nin = ((size_t) h->S * h->Tmax * h->B + 15) / 16 * 16, nir = ((size_t) h->P * h->B + 15) / 16 * 16;
+                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
                     h->bar_ir = h->bar_in + nin;
-                    h->bytes += sizeof(float) * (nin + nir);
+                    h->bar_mb = reinterpret_cast<irb::RtMailbox *>(h->bar_ir + nir);
+                    h->bytes += sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox);
+                    std::memset(h->bar_mb, 0, sizeof(irb::RtMailbox));          // through the BAR, like everything the host puts there
+                    __builtin_ia32_sfence();
+                    if ((h->flags & IRB_FDL_RESIDENT) && hipStreamCreateWithFlags(&h->rt_stream, hipStreamNonBlocking) == hipSuccess) {
+                        h->resident = true;
+                        h->idle_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_IDLE_US", 20000)) * 100u;
+                        h->life_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_LIFE_MS", 10000)) * 100000u;
+                    }
                 } else {
                     (void) hipGetLastError();                    // no such memory here: the pinned staging serves
                     h->bar_in = nullptr;
@@ -563,6 +622,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
         return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
     for (int c = 0; c < ir_channels; c++) if (!ir[c] && len > 0) return fail(IRB_ERR_ARG, "ir[%d] is null", c);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     // Asynchronous: the IR goes through one of two pinned staging slots, and the only wait is for the work that read
     // THIS slot two calls ago (an event, not the stream), so a host thread loading thousands of IRs keeps the copy
     // engine and the FFT kernel busy instead of waiting three times per instance.
@@ -612,6 +672,7 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
     if (instance < 0 || instance >= h->I) return fail(IRB_ERR_ARG, "instance %d out of range", instance);
     if (partition < 0 || partition >= h->P) return fail(IRB_ERR_ARG, "partition %d out of range [0,%d)", partition, h->P);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     const int first_set = instance * h->C;
     // the staging slot of this partition: a call may be enqueued for P distinct partitions before anything is synchronised;
     // a second refresh of the SAME partition slot (another instance, or the same one again) first waits for the stream,
@@ -653,6 +714,7 @@ int irb_fdl_get_ir_spectra(irb_fdl *h, int instance, int channel, float *spectra
     if (n_partitions < 0 || n_partitions > h->h_np_of_set[set])
         return fail(IRB_ERR_ARG, "n_partitions %d exceeds the %d partitions held", n_partitions, h->h_np_of_set[set]);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     HIP_TRY(COPY_ASYNC(h, spectra, h->d_H + (size_t) set * h->Ppad * h->M, sizeof(float2) * (size_t) n_partitions * h->M,
                            hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(irb_sync(h));
@@ -667,6 +729,7 @@ int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra
     if (!((ir_channels == 1 || (ir_channels == 2 && h->C == 2)) && (h->C == 1 || h->C == 2)))
         return fail(IRB_ERR_LAYOUT, "spectra for %d IR channels cannot feed %d audio channels", ir_channels, h->C);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     const int first_set = instance * h->C, np = n_partitions;
     for (int r = 0; r < ir_channels; r++) {
         if (!spectra[r] && np > 0) return fail(IRB_ERR_ARG, "spectra[%d] is null", r);
@@ -689,6 +752,7 @@ int irb_fdl_reset(irb_fdl *h)
 {
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream));
     if (h->d_gran)                                  // the step counter restarts, and with it the granule tags
@@ -704,6 +768,7 @@ int irb_fdl_process_device(irb_fdl *h, const float *d_in, float *d_out, long str
     if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
     if (stride < (long) n_blocks * h->B && h->S > 1) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     for (int j = 0; j < n_blocks;) {
         const int T = h->stepwise ? 1 : std::min(n_blocks - j, h->Tmax);
         irb::StepArgs a = step_args(h, d_in + (size_t) j * h->B, d_out + (size_t) j * h->B, stride);
@@ -719,6 +784,7 @@ int irb_fdl_synchronize(irb_fdl *h)
 {
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     HIP_TRY(irb_sync(h));
     return check_status(h);
 }
@@ -728,6 +794,7 @@ int irb_fdl_synchronize(irb_fdl *h)
 static int process_chunk_begin(irb_fdl *h, const float *const *in, int done, int nb)
 {
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) nb * h->B;
     for (int s = 0; s < h->S; s++) std::memcpy(h->h_io + (size_t) s * stride, in[s] + (size_t) done * h->B, sizeof(float) * n);
@@ -817,6 +884,46 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
     const bool one_launch = h->host_io && h->I == 1 && h->pair && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
                             !(h->flags & IRB_FDL_NO_RT_KERNEL);
     if (h->ir_used[0]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[0])); h->ir_used[0] = false; }   // slot 0 of the IR staging is about to be rewritten
+    if (one_launch && h->resident) {
+        // the resident server: post the request into the BAR mailbox (samples and parameters, a store fence, the request
+        // number), make sure a server generation is alive, spin on the completion word
+        for (int s = 0; s < h->S; s++) std::memcpy(h->bar_in + (size_t) s * stride, in[s], sizeof(float) * n);
+        for (int j = 0; j < n_blocks; j++) {
+            const int p = (first_partition + j) % h->P;
+            std::memcpy(h->bar_ir + (size_t) p * h->B, ir + (size_t) p * h->B, sizeof(float) * h->B);
+        }
+        unsigned seq = ++h->done_seq;
+        if (seq == 0) seq = ++h->done_seq;
+        h->bar_mb->n_blocks = n_blocks; h->bar_mb->first_partition = first_partition; h->bar_mb->head = (int) (h->t % h->R);
+        __builtin_ia32_sfence();
+        h->bar_mb->seq = seq;
+        __builtin_ia32_sfence();
+        volatile unsigned *done = h->h_done, *exited = exited_word(h);
+        if (!h->server_live || *exited == h->server_gen) { int rc = server_launch(h, seq); if (rc != IRB_OK) return rc; }
+        h->n_waits++;
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0; *done != seq; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 255u) != 255u) continue;
+            if (*exited == h->server_gen && *done != seq) {          // that generation left (idle / lifetime) without this request: the next one takes it
+                int rc = server_launch(h, seq);
+                if (rc != IRB_OK) return rc;
+                continue;
+            }
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000000L) {
+                (void) server_stop(h);
+                return fail(IRB_ERR_STATE, "real-time server did not answer within 200 ms");
+            }
+        }
+        h->t += n_blocks;
+        const float *res = h->h_io + (size_t) h->S * stride;
+        for (int s = 0; s < h->S; s++) std::memcpy(out[s], res + (size_t) s * stride, sizeof(float) * n);
+        return IRB_OK;
+    }
+    STOP_SERVER(h);
     if (one_launch) {
         // blocks and IR partitions: stored by this thread straight into device memory where the BAR allows it (write-only,
         // write-combined; the fence below drains the combining buffers before the launch's doorbell), else left in mapped
@@ -877,6 +984,7 @@ int irb_fdl_process_packed(irb_fdl *h, const float *in, float *out, long stride,
     if (n_blocks < 0) return fail(IRB_ERR_ARG, "n_blocks < 0");
     if (stride < (long) n_blocks * h->B) return fail(IRB_ERR_ARG, "stride %ld smaller than n_blocks*block", stride);
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     const long dstride = (long) h->Tmax * h->B;
     for (int done = 0; done < n_blocks; done += h->Tmax) {
         const int nb = std::min(h->Tmax, n_blocks - done);
@@ -931,6 +1039,7 @@ int irb_fdl_upload(irb_fdl *h, float *d_dst, const float *src, size_t n)
 {
     if (!h || !d_dst || !src) return fail(IRB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     HIP_TRY(COPY_ASYNC(h, d_dst, src, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(irb_sync(h));
     return IRB_OK;
@@ -940,6 +1049,7 @@ int irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n)
 {
     if (!h || !dst || !d_src) return fail(IRB_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    STOP_SERVER(h);
     HIP_TRY(COPY_ASYNC(h, dst, d_src, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(irb_sync(h));
     return IRB_OK;

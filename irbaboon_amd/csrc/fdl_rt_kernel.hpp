@@ -13,6 +13,7 @@
 // between workgroups), and the last thing the kernel does is a system-scope store of `done_seq` to a host-mapped word:
 // the audio thread spins on that word instead of entering the runtime's wait.  One launch and one wait per callback
 // whatever the host block size (round 2: two launches and one runtime wait per 256-sample block).
+// k_rt_server<N>: the same blocks served by a workgroup that stays resident between callbacks (no launch at all), below.
 #pragma once
 
 namespace irb {
@@ -26,12 +27,29 @@ struct LdsRt {
     float2 scratch[2][MacGeom<N>::STRIPES * M];        // new audio spectra, then the stripe partials
 };
 
-template <int N>
-__global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
+// one sample the host may have stored through the BAR while a resident kernel was already running: system scope, past
+// every cache of the device (a plain load could be served from a line the kernel fetched for the previous request)
+template <bool SYS>
+__device__ __forceinline__ float ld_sample(const float *p)
+{
+    if (SYS) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    return *p;
+}
+
+template <int N, bool SYS>
+__device__ __forceinline__ void rt_load_x(BlockIo<N> &io, const float *__restrict__ xin, int B, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < BlockIo<N>::XL; i++) io.x[i] = ld_sample<SYS>(xin + min(lane + i * kWave, B - 1));
+}
+
+// T blocks of one stereo instance (workgroup blockIdx.x), block j refreshing partition (rf_part + j) mod np first; the
+// twiddle table is in lds.tw (staged by the caller, covered by the first barrier here)
+template <int N, bool SYS>
+__device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int T, int head0, int rf_part)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2, U = 4;
-    __shared__ LdsRt<N> lds;
     const int s0 = 2 * blockIdx.x;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int2 si = a.stream_info[s0];
@@ -43,17 +61,21 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
     const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
     const float4 *hnew4 = reinterpret_cast<const float4 *>(lds.hnew);
 
-    stage_twiddles<N>(a.tw, lds.tw);                   // once for every block of the call (first barrier below covers it)
-
-    // samples of the first block + the saved overlaps (waves 0, 1), of the first IR partition (wave 2): they come from host
-    // memory, a PCIe round trip each.  Later blocks' samples are asked for one block ahead (below); the overlap stays in registers.
+    // samples of the first block + the saved overlaps (waves 0, 1), of the first IR partition (wave 2).  Later blocks' samples
+    // are asked for one block ahead (below); the overlap stays in registers.
     BlockIo<N> io;
-    if (wave < 2) io.load(a.in + (size_t) (s0 + wave) * a.in_stride, a.ovl + (size_t) (s0 + wave) * a.B, a.B, lane);
-    else if (wave == 2) io.load_x(a.rf_src + (size_t) (np > 0 ? a.rf_part % np : 0) * a.B, a.B, lane);
+    if (wave < 2) {
+        rt_load_x<N, SYS>(io, a.in + (size_t) (s0 + wave) * a.in_stride, a.B, lane);
+        const float *ov = a.ovl + (size_t) (s0 + wave) * a.B;
+#pragma unroll
+        for (int i = 0; i < BlockIo<N>::XL; i++) io.ov[i] = ov[min(lane + i * kWave, a.B - 1)];
+    } else if (wave == 2) {
+        rt_load_x<N, SYS>(io, a.rf_src + (size_t) (np > 0 ? rf_part % np : 0) * a.B, a.B, lane);
+    }
 
-    for (int j = 0; j < a.T; j++) {
-        const int head = (a.head + j) % a.R;
-        const int rp = np > 0 ? (a.rf_part + j) % np : 0;
+    for (int j = 0; j < T; j++) {
+        const int head = (head0 + j) % a.R;
+        const int rp = np > 0 ? (rf_part + j) % np : 0;
         // rows that meet operands still in flight: H row 0 (partition 0 pairs with this block's spectra) and the FDL rows
         // the refreshed partition pairs with
         int slot_r = head - rp;
@@ -99,9 +121,9 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
         }
 
         if (wave < 3) io.block_to_lds(lds.buf[wave], a.B, lane);
-        if (j + 1 < a.T) {                             // the next block's samples land while this block is transformed
-            if (wave < 2) io.load_x(a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) (j + 1) * a.B, a.B, lane);
-            else if (wave == 2) io.load_x(a.rf_src + (size_t) (np > 0 ? (a.rf_part + j + 1) % np : 0) * a.B, a.B, lane);
+        if (j + 1 < T) {                               // the next block's samples land while this block is transformed
+            if (wave < 2) rt_load_x<N, SYS>(io, a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) (j + 1) * a.B, a.B, lane);
+            else if (wave == 2) rt_load_x<N, SYS>(io, a.rf_src + (size_t) (np > 0 ? (rf_part + j + 1) % np : 0) * a.B, a.B, lane);
         }
         // barriers inside a block order LDS traffic only (lds_barrier: no vmcnt drain), so those loads stay in flight
         lds_barrier();
@@ -142,9 +164,79 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
         // the next block of this call reads them; one workgroup, one CU: a workgroup barrier is the whole hand-off
         __syncthreads();
     }
+}
+
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
+{
+    __shared__ LdsRt<N> lds;
+    stage_twiddles<N>(a.tw, lds.tw);                   // once for every block of the call (first barrier of rt_blocks covers it)
+    rt_blocks<N, false>(a, lds, a.T, a.head, a.rf_part);
     if (a.done != nullptr && threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the output blocks reach host memory before the word
         __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rt_server: the same callback WITHOUT a launch per callback (opt-in, IRB_FDL_RESIDENT).  A launch + dispatch + completion
+// signal cost ~8 us on this system for an empty kernel (tools/bar_probe.hip) -- two thirds of the one-launch callback.  Here
+// one workgroup stays resident and serves requests the audio thread posts into a mailbox in BAR-mapped device memory:
+// inputs and IR partitions first, then {n_blocks, first_partition, head}, a store fence, then the request number.  Thread 0
+// polls the request number with system-scope loads (s_sleep between polls); the workgroup runs rt_blocks and answers with
+// the same completion word as k_rt_pair.  Every wave reaches an exit: a quit word (the host stops the server before any
+// other call touches the engine), an idle timeout (no request for idle_ticks of the 100 MHz clock: the transport stopped),
+// and a lifetime cap.  The kernel's last act is a system-scope store of its generation to `exited`: a host that posted a
+// request while the server was on its way out sees that word with the request unanswered and launches the next
+// generation, whose first request it is -- a request is therefore served exactly once.
+// ---------------------------------------------------------------------------------------------
+struct RtMailbox {
+    unsigned seq;                                      // request number, written LAST by the host
+    int      n_blocks, first_partition, head;
+    unsigned quit;
+    unsigned pad[11];
+};
+
+template <int N>
+__global__ __launch_bounds__(kThreads) void k_rt_server(StepArgs a, const RtMailbox *mb, unsigned *exited, unsigned gen,
+                                                         unsigned first_seq, unsigned idle_ticks, unsigned life_ticks)
+{
+    __shared__ LdsRt<N> lds;
+    __shared__ int l_cmd[4];
+    stage_twiddles<N>(a.tw, lds.tw);
+    const unsigned long long born = __builtin_amdgcn_s_memrealtime();
+    for (unsigned next = first_seq;; next = next + 1 == 0 ? 1 : next + 1) {
+        if (threadIdx.x == 0) {
+            int cmd = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                if (__hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == next) { cmd = 1; break; }
+                if (__hip_atomic_load(&mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (now - t0 > idle_ticks || now - born > life_ticks) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (cmd) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                l_cmd[1] = __hip_atomic_load(&mb->n_blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                l_cmd[2] = __hip_atomic_load(&mb->first_partition, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                l_cmd[3] = __hip_atomic_load(&mb->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            l_cmd[0] = cmd;
+        }
+        __syncthreads();
+        const int cmd = l_cmd[0], T = l_cmd[1], part = l_cmd[2], head = l_cmd[3];
+        __syncthreads();                               // l_cmd may be rewritten by thread 0 as soon as it polls again
+        if (!cmd) break;
+        rt_blocks<N, true>(a, lds, T, head, part);     // ends with a barrier behind every wave's drained stores
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(a.done, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(exited, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

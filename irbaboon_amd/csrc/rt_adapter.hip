@@ -120,9 +120,12 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     cfg.max_ir_len = p->P * p->B; cfg.max_blocks_per_call = p->maxBlocks;
     // the callback's blocks are stepped one by one (rolling IR refresh between them) but enqueued together; kernels read /
     // write the pinned staging directly (no copy round trips)
-    cfg.flags = IRB_FDL_HOST_IO | IRB_FDL_STEPWISE;
+    // ... and, where the BAR lets the host store into device memory, by a workgroup that stays resident between callbacks (no launch
+    // per callback; it leaves by itself 20 ms after the last callback); IRB_RT_RESIDENT=0: one launch per callback
+    cfg.flags = IRB_FDL_HOST_IO | IRB_FDL_STEPWISE | IRB_FDL_RESIDENT;
     if (const char *v = std::getenv("IRB_RT_HOST_IO")) { if (std::atoi(v) == 0) cfg.flags &= ~IRB_FDL_HOST_IO; }     // A/B
     if (const char *v = std::getenv("IRB_RT_ONE_LAUNCH")) { if (std::atoi(v) == 0) cfg.flags |= IRB_FDL_NO_RT_KERNEL; }   // A/B
+    if (const char *v = std::getenv("IRB_RT_RESIDENT")) { if (std::atoi(v) == 0) cfg.flags &= ~IRB_FDL_RESIDENT; }        // A/B
     return irb_fdl_create(&cfg, &p->eng);
 }
 

@@ -39,10 +39,11 @@ def test_c_example_runs_on_gpu(hip_lib):
 
 @pytest.mark.gpu
 def test_c_rt_example_runs_on_gpu(hip_lib):
-    """the plug-in callback driven from plain C: delta IR = pure delay of latency + 100 samples at host blocks 256 and 512,
-    and every callback is one launch and one wait"""
+    """the plug-in callback driven from plain C: delta IR = pure delay of latency + 100 samples at host blocks 256 and 512;
+    every callback is one wait and no launch (resident server) or, with IRB_RT_RESIDENT=0, one launch"""
     _build(hip_lib)
-    r = subprocess.run([EXE_RT], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    lines = [l for l in r.stdout.splitlines() if l.startswith("host block")]
-    assert len(lines) == 2 and all("1.00 launches, 1.00 waits, 0.00 copies" in l for l in lines), r.stdout
+    for resident, want in (("1", "0.00 launches, 1.00 waits, 0.00 copies"), ("0", "1.00 launches, 1.00 waits, 0.00 copies")):
+        r = subprocess.run([EXE_RT], capture_output=True, text=True, timeout=300, env=dict(os.environ, IRB_RT_RESIDENT=resident))
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("host block")]
+        assert len(lines) == 2 and all(want in l for l in lines), r.stdout

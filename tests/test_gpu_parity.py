@@ -166,6 +166,7 @@ def test_rt_one_launch_callback_matches_two_launch_path_and_oracle(monkeypatch, 
     n_cb = max(24, 256 * 40 // host_block)
     x = np.stack([white_noise(43, n_cb * host_block), white_noise(44, n_cb * host_block)])
     outs, counts = [], []
+    monkeypatch.setenv("IRB_RT_RESIDENT", "0")            # this test is about the launches; the resident server has its own
     for one in ("1", "0"):
         monkeypatch.setenv("IRB_RT_ONE_LAUNCH", one)
         gpu = RtConvolver(2, 256, 2048)
@@ -261,6 +262,74 @@ def test_rt_kernel_block_sizes_against_float64_model(B, P, nb, first):
                     ref[c, t * B:t * B + 2 * B - 1] += seg
     for c in range(2):
         assert rel_rms(outs[0][c], ref[c, :T * B]) < RMS_TOL
+
+
+@pytest.mark.parametrize("idle_us,life_ms", [(20000, 1000), (30, 1000), (20000, 1)], ids=["steady", "idle_exits", "lifetime_exits"])
+@pytest.mark.parametrize("host_block", [64, 256, 512])
+def test_rt_resident_server_matches_one_launch_callback(monkeypatch, host_block, idle_us, life_ms):
+    """IRB_RT_RESIDENT=1: the callback served by a workgroup that stays on the GPU between callbacks (k_rt_server, requests
+    through a BAR mailbox) -- the same samples, bit for bit, as the one-launch callback, also when the server keeps leaving
+    (30 us idle timeout with pauses between callbacks; 1 ms lifetime) and the next request has to start a new generation,
+    with the IR replaced in mid-stream, a bypassed block and a reset-free prepareToPlay in between.  No kernel launch per
+    callback in the steady case; the process must end without a hang (the server's exits are part of the test)."""
+    import time
+    irs = [decaying_ir(5, 8 * 256), decaying_ir(6, 8 * 256)[::-1].copy()]
+    n_cb = max(30, 256 * 30 // host_block)
+    x = np.stack([white_noise(45, n_cb * host_block), white_noise(46, n_cb * host_block)])
+    outs, launches = [], []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("IRB_RT_RESIDENT", resident)
+        monkeypatch.setenv("IRB_RT_SERVER_IDLE_US", str(idle_us))
+        monkeypatch.setenv("IRB_RT_SERVER_LIFE_MS", str(life_ms))
+        gpu = RtConvolver(2, 256, 2048)
+        gpu.prepareToPlay(host_block)
+        y = np.empty_like(x)
+        for k in range(n_cb):
+            if k in (3, n_cb // 2):
+                gpu.setIR(irs[k == 3])
+            if resident == "1" and idle_us < 1000 and k % 5 == 0:
+                time.sleep(0.002)                               # long enough for the idle timeout: the server is gone at the next callback
+            a = np.ascontiguousarray(x[:, k * host_block:(k + 1) * host_block])
+            gpu.processBlock(a)
+            y[:, k * host_block:(k + 1) * host_block] = a
+            if k == 9:
+                c0 = gpu.counters()
+        c1 = gpu.counters()
+        launches.append((c1[1] - c0[1]) / (c1[0] - c0[0]))
+        outs.append(y)
+        gpu.close()                                             # stops a live server (quit word), then frees
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
+    if idle_us >= 1000 and life_ms >= 100:
+        assert launches[0] < 0.1 * min(1.0, host_block / 256)    # steady state: (almost) no launches at all
+    assert launches[1] >= min(1.0, host_block / 256) - 0.05
+
+
+def test_resident_server_yields_to_every_other_entry_point():
+    """While the resident server runs it owns the engine; any other call (here: reset, a plain process call, set_ir_partition,
+    synchronize) first stops it through the quit word -- no hang, and the samples afterwards are those of an engine that never
+    had a server."""
+    B, P, nb = 256, 8, 2
+    x = _streams(1, 2, 12 * nb * B, 9600)
+    h = decaying_ir(9650, P * B)
+    outs = []
+    for flags in (_lib.HOST_IO | _lib.STEPWISE | _lib.RESIDENT, _lib.HOST_IO | _lib.STEPWISE):
+        with FdlEngine(1, 2, B, P * B, max_blocks_per_call=nb, flags=flags) as eng:
+            ys, part = [], 0
+            for k in range(12):
+                xs = x[:, k * nb * B:(k + 1) * nb * B]
+                if k == 4:
+                    eng.synchronize()
+                if k == 6:
+                    ys.append(eng.process(xs))                  # the plain step path in the middle of the refresh calls
+                    continue
+                if k == 8:
+                    eng.set_ir_partition(0, 3, h[3 * B:4 * B] * 0.5)
+                ys.append(eng.process_refresh(xs, h, part))
+                part = (part + nb) % P
+            eng.reset()
+            ys.append(eng.process_refresh(x[:, :nb * B], h, 0))
+            outs.append(np.concatenate(ys, axis=1))
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
 
 
 def test_rt_adapter_host_block_larger_than_block_is_causal():

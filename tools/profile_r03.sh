@@ -28,6 +28,6 @@ echo "== time-tiled MAC: counters, stamps"
 for a in "3750 2" "3750 1" "3750 4" "940 8" "7500 1"; do timeout -k 5 60 ./tools/tiled_stamps $a; done > $O/tiled_stamps.txt 2>&1
 ./tools/valu_peak > $O/valu_peak.txt 2>&1
 echo "== real-time callback A/B, hand-off soak"
-for hb in 64 256 512 1024; do python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_ONE_LAUNCH=0 python3 tools/perf_probe.py rtc $hb 3000; done > $O/rt_ab.txt 2>&1
+for hb in 64 256 512 1024; do python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 IRB_RT_BAR=0 python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 IRB_RT_ONE_LAUNCH=0 python3 tools/perf_probe.py rtc $hb 3000; done > $O/rt_ab.txt 2>&1
 timeout -k 10 300 python3 tools/handoff_under_load.py > $O/handoff_under_load.txt 2>&1; tail -2 $O/handoff_under_load.txt
 echo done
