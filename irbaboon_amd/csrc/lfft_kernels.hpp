@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, con
     const float2 *X = reinterpret_cast<const float2 *>(spec + b * 2 * a.N);
     float2 *dst = out + b * M;
 
+    __shared__ float2 l_w2[R];                               // W_N^n2 of the tile's columns
     float2 twv[TPT];
     // inter-pass factor of this wave's column (needed after the column transform): asked for at the top
     constexpr int KPL = MX >= kWave ? MX / kWave : 1;
@@ -324,19 +325,35 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, con
             wb2[i] = a.tabB[e & ((1u << a.logE) - 1u)];
         }
     }
+    float2 c2a = make_float2(1.f, 0.f), c2b = c2a;
+    if (threadIdx.x < R) {
+        const unsigned n2 = (unsigned) (i0 + threadIdx.x);
+        c2a = a.tabA[n2 >> a.logE];
+        c2b = a.tabB[n2 & ((1u << a.logE) - 1u)];
+    }
 #pragma unroll
     for (int i = 0; i < TPT; i++) twv[i] = a.tw1[min((int) threadIdx.x + i * NT, MX - 1)];
 #pragma unroll 1
     for (int c0 = 0; c0 < EPT; c0 += CH) {
-        float2 p[CH], q[CH], wa[CH], wb[CH];
+        float2 p[CH], q[CH];
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             const int idx = min((int) threadIdx.x + (c0 + i) * NT, MX * R - 1);
             const int e = (idx / R) * M2 + i0 + idx % R;                            // x[n1*M2 + n2]: R contiguous n2 per n1
             p[i] = X[e];
             q[i] = X[M - e];                                                         // e = 0 reads the Nyquist bin X[M]
-            wa[i] = a.tabA[(unsigned) e >> a.logE];
-            wb[i] = a.tabB[(unsigned) e & ((1u << a.logE) - 1u)];
+        }
+        if (c0 == 0) {
+            // the split twiddle W_N^e, e = n1*M2 + n2, is W_N^n2 (one value per tile column) times W_N^(n1*M2) = W_(2*M1)^n1 -- the
+            // column transform's own table, staged in LDS while the first bins are in flight (round 2 fetched two table entries
+            // from global memory per element)
+#pragma unroll
+            for (int i = 0; i < TPT; i++) {
+                const int idx = threadIdx.x + i * NT;
+                if (idx < MX) put_twiddle<2 * MX>(l_tw, idx, twv[i]);
+            }
+            if (threadIdx.x < R) l_w2[threadIdx.x] = cmul(c2a, c2b);
+            __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < CH; i++) {
@@ -351,17 +368,12 @@ __global__ __launch_bounds__(kWave * R) void k_lfft_cols_unsplit(LfftArgs a, con
                 } else {
                     const float2 ev = make_float2(p[i].x + q[i].x, p[i].y - q[i].y);        // p + conj q
                     const float2 d = make_float2(p[i].x - q[i].x, p[i].y + q[i].y);         // p - conj q
-                    const float2 o = cmulc(d, cmul(wa[i], wb[i]));                          // * W_N^{-e}
+                    const float2 o = cmulc(d, cmul(l_w2[idx % R], l_tw[idx / R]));          // * W_N^{-e}
                     z = make_float2(ev.x - o.y, ev.y + o.x);
                 }
                 tile[(idx % R) * LD + idx / R] = z;
             }
         }
-    }
-#pragma unroll
-    for (int i = 0; i < TPT; i++) {
-        const int idx = threadIdx.x + i * NT;
-        if (idx < MX) put_twiddle<2 * MX>(l_tw, idx, twv[i]);
     }
     __syncthreads();
     float2 *mine = tile + wave * LD;
