@@ -953,6 +953,35 @@ def test_back_to_back_steps_without_host_sync(monkeypatch, geom, ho):
             assert rel_rms(y[i * C + c], ref) < RMS_TOL
 
 
+@pytest.mark.parametrize("flags", [_lib.HOST_IO, 0], ids=["host_io", "copy"])
+def test_ir_staging_is_not_overwritten_before_it_is_read(flags):
+    """the pinned IR staging slot of irb_fdl_set_ir_partition is indexed by partition only.  Three instances refresh the SAME
+    partition index back to back with different samples and nothing waits in between; then whole IRs are set for all instances back
+    to back (irb_fdl_set_ir is asynchronous: two staging slots, an event per slot).  Every instance must convolve with ITS samples."""
+    I, B, P, T = 3, 128, 4, 6
+    x = _streams(I, 1, T * B, 9800)
+    parts = [decaying_ir(9810 + i, B) for i in range(I)]
+    with FdlEngine(I, 1, B, P * B, max_blocks_per_call=1, flags=flags) as eng:
+        for rep in range(2):                                          # the second round reuses slots that are certainly still in flight
+            for i in range(I):
+                eng.set_ir_partition(i, 2, parts[i] * (rep + 1))
+        y = eng.process(x)
+        for i in range(I):
+            h = np.zeros(P * B, np.float32)
+            h[2 * B:3 * B] = parts[i] * 2
+            ref = scipy.signal.fftconvolve(x[i].astype(np.float64), h.astype(np.float64))[:T * B]
+            assert rel_rms(y[i], ref) < RMS_TOL
+        irs = [decaying_ir(9820 + i, P * B - 7 * i) for i in range(I)]
+        for rep in range(3):
+            for i in range(I):
+                eng.set_ir(i, irs[(i + rep) % I])                    # nine uploads through two staging slots, no wait requested
+        eng.reset()
+        y = eng.process(x)
+        for i in range(I):
+            ref = scipy.signal.fftconvolve(x[i].astype(np.float64), irs[(i + 2) % I].astype(np.float64))[:T * B]
+            assert rel_rms(y[i], ref) < RMS_TOL
+
+
 @pytest.mark.parametrize("case", [(1, 2, 256, 2048, 12, 1), (2, 1, 128, 3000, 9, 4), (1, 1, 64, 500, 20, 1)], ids=lambda c: "I%d_C%d_B%d_Lh%d_T%d_tmax%d" % c)
 def test_host_io_mode_matches_copy_mode(case):
     """IRB_FDL_HOST_IO: kernels read blocks and IR partitions from, and write output blocks to, mapped pinned host memory
