@@ -126,10 +126,10 @@ def rt(host_block=256, n=2000):
           f"(deadline {host_block/48000*1e6:.0f} us at 48 kHz)")
 
 
-def rtc(host_block=256, n=3000):
+def rtc(host_block=256, n=3000, ir_ring_len=2048, channels=2):
     """the same callbacks timed in C (irb_rt_time_callbacks): what bench.py's rt_processBlock entry reports"""
     from irbaboon_amd import RtConvolver
-    r = RtConvolver(2, 256, 2048)
+    r = RtConvolver(channels, 256, ir_ring_len)
     r.prepareToPlay(host_block)
     r.time_callbacks(host_block, 200)
     c0 = r.counters()
@@ -137,7 +137,7 @@ def rtc(host_block=256, n=3000):
     c1 = r.counters()
     cb = c1[0] - c0[0]
     env = {k: v for k, v in os.environ.items() if k.startswith("IRB_")}
-    print(f"rt adapter (C loop) hostBlock={host_block} {env}: median {np.median(ts):.1f} us, p99 {np.percentile(ts, 99):.1f} us, max {ts.max():.1f} us; "
+    print(f"rt adapter (C loop) hostBlock={host_block} ring={ir_ring_len} ch={channels} {env}: median {np.median(ts):.1f} us, p99 {np.percentile(ts, 99):.1f} us, max {ts.max():.1f} us; "
           f"per callback: {(c1[1]-c0[1])/cb:.2f} launches, {(c1[2]-c0[2])/cb:.2f} waits, {(c1[3]-c0[3])/cb:.2f} copies")
 
 
