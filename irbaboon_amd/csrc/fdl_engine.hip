@@ -213,12 +213,21 @@ void choose_path(irb_fdl *h)
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
 constexpr int kPadP = irb::kTilePeriod;       // H rows per set: P rounded up to this (a multiple of kTT); the extra rows stay zero
 
+// outputs per time tile for a call of T blocks: 16, or 8 when the call has no more than 8 blocks (a 16-output tile would multiply
+// eight outputs nobody keeps: on HBM-sized batches of 8-block calls the MAC is then as expensive as the row traffic)
+int tile_outputs(const irb_fdl *h, int T)
+{
+    if (h->tiled_kernel == 0) return kTT;
+    return (T <= 8 && env_int("IRB_TILED_TT8", 1)) ? 8 : h->tileTT;
+}
+
 // partition splits for a call of T blocks: enough workgroups to fill the chip, but every stripe keeps
 // at least two full window steps of partitions
 int tiled_splits(const irb_fdl *h, int T)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
-    const int ntiles = (T + h->tileTT - 1) / h->tileTT;
+    const int tt = tile_outputs(h, T);
+    const int ntiles = (T + tt - 1) / tt;
     const int by_work = h->tiled_kernel == 0 ? std::max(1, (h->Ppad / kTT) / (stripes * 2))
                                              : std::max(1, (h->Ppad / kPadP) / stripes);     // every worker at least one ring period
     const long wgs = (long) h->S * ntiles;
@@ -334,7 +343,8 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     if (one_bin) a.nq = a.splits * stripes1;
     else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
-    const int ntiles = one_bin ? (T + 15) / 16 : (T + h->tileTT - 1) / h->tileTT;
+    const int tt = tile_outputs(h, T);
+    const int ntiles = one_bin ? (T + 15) / 16 : (T + tt - 1) / tt;
     const dim3 mac_grid(h->S * ntiles * a.splits), mac_block(irb::kThreads);
     h->n_launches += 3;
     FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
@@ -345,6 +355,8 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
         if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
         else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     }
+    else if (tt == 8 && nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (tt == 8)        { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else          { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((T + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
