@@ -337,23 +337,26 @@ def config5(dev, np):
 
     def wall(fn, reps):
         fn()                                        # first call builds the cached plan
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             fn()
-        return (time.perf_counter() - t0) / reps * 1e3
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3           # median: one host hiccup in five calls must not become the number
 
-    t_raw = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=False, device=dev), 10)
-    t_smooth = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=True, device=dev), 5)
+    t_raw = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=False, device=dev), 11)
+    t_smooth = wall(lambda: ib.deconvolve(cap, sweep, sr, smoothing=True, device=dev), 9)
     ir = ib.deconvolve(cap, sweep, sr, smoothing=False, device=dev)
-    t_inv = wall(lambda: ib.invertFilter(ir, sr, device=dev), 5)
+    t_inv = wall(lambda: ib.invertFilter(ir, sr, device=dev), 9)
     # traffic the chain cannot avoid: two forward FFTs (read N, write N) + divide + inverse, all fp32
     res["configs[4]_2^20_deconvolve_chain"] = {
         "deconvolve_no_smoothing_ms": round(t_raw, 3), "deconvolve_default_3x_smoothing_ms": round(t_smooth, 3),
         "invert_filter_ms": round(t_inv, 3), "samples": N,
         "Msamples_per_s_default": round(N / t_smooth / 1e3, 1),
         "effective_GBps_end_to_end_no_smoothing": round(3 * 4.0 * N / t_raw / 1e6, 1),     # 2 signals in + 1 out over PCIe, fp32
-        "device_time": "per-kernel durations of this chain: profiles/r02_lfft_kernel_stats.csv (FFT passes 5-10 us each); the default "
-                       "chain's time is 3 x (2 MB D2H + ~1.5 ms sequential float running sum on the host + 2 MB H2D)",
+        "device_time": "per-kernel durations of this chain: profiles/r03_lfft_kernel_stats.csv (FFT passes 7-10 us each); the default "
+                       "chain's time is 3 x ~0.9 ms of the host's sequential float running sum (log amplitudes and window means go through "
+                       "mapped pinned memory, no copy commands); medians over 9-11 calls",
         "note": "irb_deconvolve / irb_invert_filter one-shot calls on a 2^20-sample sweep capture (786432-sample sweep + silence, "
                 "4096-tap IR), wall clock from pageable host buffers incl. PCIe; fp/convolution.cpp:351-403, fp/ir.cpp:13-18"}
     ib.lib().irb_release_cached_plans()
