@@ -230,8 +230,14 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
             ent["fp32_flops"] = flops
             ent["TFLOPs"] = round(flops / ms / 1e9, 2)
             ent["frac_of_157.3"] = round(flops / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
+            # the least a call must move: every H row and every row of the FDL window (P past blocks + the call's T) once, fp32
+            min_bytes = float(I * C) * (2 * e.info.partitions + T) * e.info.fft_len * 4.0
+            ent["min_traffic_GBps"] = round(min_bytes / ms / 1e6, 1)
+            ent["frac_of_hbm_peak_min_traffic"] = round(min_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
             ent["roofline_note"] = ("whole call (forward FFTs + MAC + inverse FFTs / overlap-add) against the fp32 vector peak; "
-                                    "MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, T blocks")
+                                    "MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, T blocks.  min_traffic: H and the "
+                                    "FDL window read once per call -- the binding side of HBM-sized batches with few blocks per call "
+                                    "(cache-resident calls are VALU-bound and leave it far below 1)")
         res[name] = ent
         e.close()
 

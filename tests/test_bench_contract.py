@@ -53,6 +53,7 @@ def test_committed_bench_line_follows_contract():
             assert "algorithmic_GBps" not in e and "algorithmic_GBps_streaming_model" not in e
             assert abs(e["TFLOPs"] - e["fp32_flops"] / (e["ms_per_call"] * 1e-3) / 1e12) / e["TFLOPs"] < 2e-2
             assert abs(e["frac_of_157.3"] - e["TFLOPs"] / 157.3) < 1e-3 and e["frac_of_157.3"] < 1.0
+            assert 0 < e["frac_of_hbm_peak_min_traffic"] < 1.0
 
 
 def test_every_bench_kernel_is_launched_by_a_parity_test():
