@@ -437,7 +437,15 @@ extern "C" void irb_fdl_destroy(irb_fdl *h);
 namespace {
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;
-    ~OfflineEngineGuard() { if (eng) { irb_fdl_destroy(eng); eng = nullptr; } }
+    float *stage = nullptr;                            // pinned: two slots of [input | output][C][Tmax*B] for the chunk pipeline
+    hipEvent_t ev[2] = {nullptr, nullptr};             // recorded behind each slot's D2H copy
+    void release()
+    {
+        if (eng) { irb_fdl_destroy(eng); eng = nullptr; }
+        if (stage) { (void) hipHostFree(stage); stage = nullptr; }
+        for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
+    }
+    ~OfflineEngineGuard() { release(); }
 };
 thread_local OfflineEngineGuard g_offline;
 }
@@ -1077,13 +1085,15 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     if (!audio || !ir || !out) return fail(IRB_ERR_ARG, "null argument");
     if (La < 0 || Lh < 0 || B < 1 || audio_ch < 1) return fail(IRB_ERR_ARG, "negative length or block < 1");
     const long Lout = (long) La + Lh - 1;
-    for (int c = 0; c < audio_ch; c++) {
-        if (!out[c]) return fail(IRB_ERR_ARG, "out[%d] is null", c);
-        if (Lout > 0) std::memset(out[c], 0, sizeof(float) * (size_t) Lout);       // :20-21
-    }
-    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2)))          // :28-42
+    for (int c = 0; c < audio_ch; c++) if (!out[c]) return fail(IRB_ERR_ARG, "out[%d] is null", c);
+    auto clear_out = [&](long from) {                                               // :20-21 (what is computed below is not cleared first)
+        for (int c = 0; c < audio_ch; c++) if (Lout > from) std::memset(out[c] + from, 0, sizeof(float) * (size_t) (Lout - from));
+    };
+    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2))) {        // :28-42
+        clear_out(0);
         return fail(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
-    if (Lh == 0 || La == 0 || Lout <= 0) return IRB_OK;     // nothing to convolve: the cleared output is the answer
+    }
+    if (Lh == 0 || La == 0 || Lout <= 0) { clear_out(0); return IRB_OK; }           // nothing to convolve: the cleared output is the answer
     // :52 -- the reference takes ceil of a float ratio; samples beyond P*B are never read (:106-118)
     const int P = (int) std::ceil((float) Lh / (float) B);
     const int Lh_eff = (int) std::min<long>(Lh, (long) P * B);
@@ -1091,53 +1101,75 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     long steps = (long) T_last + P;                   // :233
     const long written = steps * B;
     if (!keep_reference_tail && Lout > written) steps += 1;   // flush the overlap the reference drops (:236-238)
+    const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;    // samples this call produces (:225-227)
+    clear_out(lim);                                                                 // the dropped tail stays 0 (:236-238)
 
+    // The signal goes through in chunks of at most 1024 blocks, two pinned staging slots deep: while the GPU copies and
+    // convolves chunk c, this thread unpacks chunk c-2 and packs chunk c+1 (the host copies in and out of pinned memory
+    // are two thirds of a call's time; round 2 did them strictly before and after the GPU work).
+    const int nc = (int) ((steps + 1023) / 1024), Tc = (int) ((steps + nc - 1) / nc);
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
-    const int need_T = (int) std::min<long>(steps, 4096);
     irb_fdl *h = g_offline.eng;
-    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= need_T && h->Tmax <= 8 * need_T + 64)) {
-        if (h) { irb_fdl_destroy(h); g_offline.eng = nullptr; }
+    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= Tc && h->Tmax <= 8 * Tc + 64)) {
+        g_offline.release();
         irb_fdl_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = P * B;
-        cfg.max_blocks_per_call = need_T;
+        cfg.max_blocks_per_call = Tc;
         int rc0 = irb_fdl_create(&cfg, &h);
         if (rc0 != IRB_OK) return rc0;
         g_offline.eng = h;
+        const size_t slot = (size_t) 2 * audio_ch * h->Tmax * B;                     // per slot: input and output, [C][Tmax*B] each
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&g_offline.stage), sizeof(float) * 2 * slot);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev[1], hipEventDisableTiming);
+        if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline staging: %s", hipGetErrorString(e)); }
     }
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
     rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
-    if (rc == IRB_OK) {
-        const long stride = (long) h->Tmax * h->B;
-        for (long done = 0; done < steps && rc == IRB_OK; done += h->Tmax) {
-            const int nb = (int) std::min<long>(h->Tmax, steps - done);
-            const long s0 = done * B, n = (long) nb * B;
-            for (int c = 0; c < audio_ch; c++) {
-                float *dst = h->h_io + (size_t) c * stride;
-                const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));
-                if (have > 0) std::memcpy(dst, audio[c] + s0, sizeof(float) * (size_t) have);
-                std::fill(dst + have, dst + n, 0.0f);
-            }
-            hipError_t e = hipSuccess;
-            for (int c = 0; c < audio_ch && e == hipSuccess; c++)       // only the blocks of this call, per channel
-                e = COPY_ASYNC(h, h->d_in + (size_t) c * stride, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) n,
-                                   hipMemcpyHostToDevice, h->stream);
-            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-            rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
-            if (rc != IRB_OK) break;
-            for (int c = 0; c < audio_ch && e == hipSuccess; c++)
-                e = COPY_ASYNC(h, h->h_io + (size_t) c * stride, h->d_out + (size_t) c * stride, sizeof(float) * (size_t) n,
-                                   hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = irb_sync(h);
-            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
-            const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;
-            const long take = std::max<long>(0, std::min<long>(n, lim - s0));          // :225-227
-            for (int c = 0; c < audio_ch; c++)
-                if (take > 0) std::memcpy(out[c] + s0, h->h_io + (size_t) c * stride, sizeof(float) * (size_t) take);
+    if (rc != IRB_OK) return rc;
+    const long stride = (long) h->Tmax * h->B;
+    const size_t half = (size_t) audio_ch * stride;                                  // floats per staging half (input or output)
+    auto s_in = [&](int c) { return g_offline.stage + (size_t) (c & 1) * 2 * half; };
+    auto s_out = [&](int c) { return s_in(c) + half; };
+    auto chunk_blocks = [&](int c) { return (int) std::min<long>(Tc, steps - (long) c * Tc); };
+    auto unpack = [&](int c) -> int {                                               // wait for chunk c, copy its samples out
+        h->n_waits++;
+        hipError_t e = hipEventSynchronize(g_offline.ev[c & 1]);
+        if (e != hipSuccess) return fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+        const long s0 = (long) c * Tc * B, n = (long) chunk_blocks(c) * B;
+        const long take = std::max<long>(0, std::min<long>(n, lim - s0));
+        for (int ch = 0; ch < audio_ch; ch++)
+            if (take > 0) std::memcpy(out[ch] + s0, s_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) take);
+        return IRB_OK;
+    };
+    for (int c = 0; c < nc && rc == IRB_OK; c++) {
+        if (c >= 2) { rc = unpack(c - 2); if (rc != IRB_OK) break; }                 // frees the staging slot this chunk reuses
+        const int nb = chunk_blocks(c);
+        const long s0 = (long) c * Tc * B, n = (long) nb * B;
+        for (int ch = 0; ch < audio_ch; ch++) {
+            float *dst = s_in(c) + (size_t) ch * stride;
+            const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));
+            if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
+            std::fill(dst + have, dst + n, 0.0f);
         }
+        hipError_t e = hipSuccess;
+        for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)       // only the blocks of this chunk, per channel
+            e = COPY_ASYNC(h, h->d_in + (size_t) ch * stride, s_in(c) + (size_t) ch * stride, sizeof(float) * (size_t) n,
+                           hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+        rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
+        if (rc != IRB_OK) break;
+        for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)
+            e = COPY_ASYNC(h, s_out(c) + (size_t) ch * stride, h->d_out + (size_t) ch * stride, sizeof(float) * (size_t) n,
+                           hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(g_offline.ev[c & 1], h->stream);
+        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
     }
+    for (int c = std::max(0, nc - 2); c < nc && rc == IRB_OK; c++) rc = unpack(c);
+    if (rc != IRB_OK) (void) irb_sync(h);             // nothing of a failed call may still be writing the staging
     return rc;
 }
 
@@ -1228,7 +1260,7 @@ int irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const
 
 void irb_fdl_release_cached_engine_(void)
 {
-    if (g_offline.eng) { irb_fdl_destroy(g_offline.eng); g_offline.eng = nullptr; }
+    g_offline.release();
 }
 
 }  // extern "C"
