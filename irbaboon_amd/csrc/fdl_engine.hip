@@ -75,6 +75,7 @@ struct irb_fdl {
                                                          // blocks [S][Tmax*B] and IR partitions [P*B] into directly (posted writes over PCIe), so that
                                                          // k_rt_pair's first loads are local instead of PCIe round trips (tools/bar_probe.hip: -2 us per callback)
     unsigned done_seq = 0;
+    bool is_gfx950 = true;                   // the device this handle runs on reports gcnArchName gfx950 (the hand-off forms were measured there)
     bool stepwise = false;                   // IRB_FDL_STEPWISE: a call of n blocks = n one-block steps, ring of P slots
     long long cols_launches = 0, debug_drop_at = 0;   // IRB_DEBUG_DROP_GRANULES=n (tests): the n-th column-sliced launch loses one producer's granules
     unsigned long long n_launches = 0, n_waits = 0, n_copies = 0;   // what the host asked of the runtime since create (irb_fdl_get_counters)
@@ -208,6 +209,9 @@ void choose_path(irb_fdl *h)
     // 7.18 -> 6.65 us -- and lose from 32 streams on, where one reducer per stream sweeps 2048+ granules)
     h->cols_handoff = env_int("IRB_COLS_HANDOFF", (base * PS <= 256 && W < 64) ? 2 : 0);
     if (h->cols_handoff < 0 || h->cols_handoff > 2) h->cols_handoff = 0;
+    // forms 0 and 2 lean on how gfx950 acknowledges write-through stores ("Hand-off form 0"): measured there, not an
+    // architectural guarantee, so any other device gets the release / acquire fences of form 1
+    if (!h->is_gfx950 && !std::getenv("IRB_COLS_HANDOFF")) h->cols_handoff = 1;
 }
 
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
@@ -502,6 +506,10 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->Ppad = (h->P + kPadP - 1) / kPadP * kPadP;
     h->Tmax = cfg->max_blocks_per_call;
     h->flags = cfg->flags;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->is_gfx950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }
     h->stepwise = (h->flags & IRB_FDL_STEPWISE) != 0 || h->Tmax == 1;
     h->R = h->stepwise ? h->P : h->Ppad + h->Tmax + kTT;     // tiled path: P past blocks + the call's blocks + tile overhang
     choose_path(h);
