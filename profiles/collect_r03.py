@@ -2,6 +2,8 @@
 under profiles/.  HBM traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and
 WRITE_SIZE from separate --pmc passes, values in KiB, FETCH_SIZE doubled on gfx950 for wide coalesced streaming
 reads (16 B per lane), WRITE_SIZE exact.
+gpurun only ADDS files to the local gpurun_out/: remove gpurun_out/prof_r03 and gpurun_out/tiled_prof here before the profiling
+call, or files of earlier calls are mixed in.
 usage: python profiles/collect_r03.py [gpurun_out]"""
 import collections
 import csv
@@ -19,7 +21,10 @@ def stats_csv(src_dir):
     """the kernel_stats file of the profiled program itself: child processes (compiled examples, the bench's PMC
     children) leave small files of their own next to it"""
     f = glob.glob(os.path.join(src_dir, "*", "*_kernel_stats.csv"))
-    return max(f, key=os.path.getsize) if f else None
+    if not f:
+        return None
+    newest = max(os.path.getmtime(x) for x in f)               # files of one call are written within seconds of each other
+    return max((x for x in f if newest - os.path.getmtime(x) < 120), key=os.path.getsize)
 
 
 def counters(src_dir, kernel):
