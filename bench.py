@@ -266,8 +266,8 @@ def rt_process_block(dev, np):
     from irbaboon_amd import RtConvolver
     from irbaboon_amd.synth import decaying_ir
 
-    def measure(hb):
-        r = RtConvolver(2, 256, 2048, device=dev)
+    def measure(hb, channels=2):
+        r = RtConvolver(channels, 256, 2048, device=dev)
         r.prepareToPlay(hb)
         r.setIR(decaying_ir(31000, 2048))
         r.time_callbacks(hb, 300)                       # warm-up: every partition refreshed, clocks up
@@ -279,9 +279,10 @@ def rt_process_block(dev, np):
         return {"callbacks": int(cb), "median_us": round(float(np.median(us)), 2), "p99_us": round(float(np.percentile(us, 99)), 2),
                 "max_us": round(float(us.max()), 2), "launches_per_callback": round((c1[1] - c0[1]) / cb, 3),
                 "waits_per_callback": round((c1[2] - c0[2]) / cb, 3), "copies_per_callback": round((c1[3] - c0[3]) / cb, 3),
-                "deadline_us_at_48k": round(hb / 48000 * 1e6, 1), "Msamples_per_s": round(2 * hb / float(np.median(us)), 2)}
+                "deadline_us_at_48k": round(hb / 48000 * 1e6, 1), "Msamples_per_s": round(channels * hb / float(np.median(us)), 2)}
 
     out = {f"host_block_{hb}": measure(hb) for hb in (256, 512)}
+    out["mono_host_block_256"] = measure(256, channels=1)
     # the same callbacks with one kernel launch each (the form on systems whose BAR does not cover device memory, and round 3's
     # first step from round 2's two launches per block): the variable is set for these two measurements only
     saved = os.environ.get("IRB_RT_RESIDENT")

@@ -51,7 +51,7 @@ extern "C" {
 #define IRB_FDL_STEPWISE      0x40u /* a call of n <= max_blocks_per_call blocks runs n one-block steps, never the time-tiled
                                        kernels; the FDL ring then holds exactly P slots (the real-time adapter's engine)   */
 #define IRB_FDL_NO_RT_KERNEL  0x80u /* irb_fdl_process_refresh: always the refresh launch + step launch per block (A/B, tests) */
-#define IRB_FDL_RESIDENT      0x100u /* irb_fdl_process_refresh (single stereo instance, IRB_FDL_HOST_IO, large-BAR system): requests are served by
+#define IRB_FDL_RESIDENT      0x100u /* irb_fdl_process_refresh (single stereo or mono instance, IRB_FDL_HOST_IO, large-BAR system): requests are served by
                                         a workgroup that stays resident on the GPU between callbacks (no kernel launch per callback); it exits
                                         by itself after 20 ms without a request (the next callback starts a new one), after 10 s at the
                                         latest, and whenever any other entry point of the handle is called                        */
@@ -136,7 +136,7 @@ int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int 
  * of `instance` is re-derived from ir + that partition's offset (the rolling refresh, :455-461; IR channel 0 feeds every
  * audio channel, :485), then the block goes through the FDL step (:463-510).  `ir`: host pointer to P*block samples.
  * in/out as irb_fdl_process, n_blocks <= max_blocks_per_call; the handle must be IRB_FDL_STEPWISE (or one block per
- * call).  A single stereo instance created with IRB_FDL_HOST_IO and a short IR ring (the plug-in adapter's engine) runs
+ * call).  A single stereo or mono instance created with IRB_FDL_HOST_IO and a short IR ring (the plug-in adapter's engine) runs
  * the whole call as one kernel launch and waits on a host-mapped completion word; other shapes enqueue a refresh launch
  * and a step launch per block and wait once.  Blocks until done.                                                    */
 int  irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, float *const *out, int n_blocks,

@@ -399,8 +399,13 @@ int server_launch(irb_fdl *h, unsigned first_seq)
     a.rf_src = h->bar_ir; a.done = h->d_done;
     if (++h->server_gen == 0) ++h->server_gen;           // 0 is the exited word's initial value
     h->n_launches++;
-    FOR_N_RT(h->N, irb::k_rt_server<NN><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->rt_stream>>>(
-                       a, h->bar_mb, h->d_done + 1, h->server_gen, first_seq, h->idle_ticks, h->life_ticks));
+    if (h->C == 2) {
+        FOR_N_RT(h->N, irb::k_rt_server<NN, 2><<<dim3(h->I), dim3(irb::kThreads), 0, h->rt_stream>>>(
+                           a, h->bar_mb, h->d_done + 1, h->server_gen, first_seq, h->idle_ticks, h->life_ticks));
+    } else {
+        FOR_N_RT(h->N, irb::k_rt_server<NN, 1><<<dim3(h->I), dim3(irb::kThreads), 0, h->rt_stream>>>(
+                           a, h->bar_mb, h->d_done + 1, h->server_gen, first_seq, h->idle_ticks, h->life_ticks));
+    }
     HIP_TRY(hipGetLastError());
     h->server_live = true;
     return IRB_OK;
@@ -907,9 +912,9 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
 
     const long stride = (long) h->Tmax * h->B;
     const size_t n = (size_t) n_blocks * h->B;
-    // one launch for the whole call: a single stereo instance whose step runs in one workgroup, blocks and IR samples
-    // in mapped host memory (what the plug-in adapter creates)
-    const bool one_launch = h->host_io && h->I == 1 && h->pair && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
+    // one launch for the whole call: a single stereo or mono instance whose step runs in one workgroup, blocks and IR
+    // samples in mapped host memory (what the plug-in adapter creates)
+    const bool one_launch = h->host_io && h->I == 1 && (h->pair || h->C == 1) && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
                             !(h->flags & IRB_FDL_NO_RT_KERNEL);
     if (h->ir_used[0]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[0])); h->ir_used[0] = false; }   // slot 0 of the IR staging is about to be rewritten
     if (one_launch && h->resident) {
@@ -968,7 +973,8 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
         a.done = h->d_done; a.done_seq = ++h->done_seq;
         if (a.done_seq == 0) a.done_seq = ++h->done_seq;            // 0 is the word's initial value
         h->n_launches++;
-        FOR_N_RT(h->N, irb::k_rt_pair<NN><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a));
+        if (h->C == 2) { FOR_N_RT(h->N, irb::k_rt_pair<NN, 2><<<dim3(h->I), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else           { FOR_N_RT(h->N, irb::k_rt_pair<NN, 1><<<dim3(h->I), dim3(irb::kThreads), 0, h->stream>>>(a)); }
         HIP_TRY(hipGetLastError());
         h->t += n_blocks;
         h->n_waits++;

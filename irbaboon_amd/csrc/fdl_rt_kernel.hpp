@@ -1,8 +1,9 @@
 // fdl_rt_kernel.hpp -- the real-time callback of the plug-in (reference Source/PluginProcessor.cpp:452-518) as ONE launch.
 // Included by fdl_kernels.hpp.
 //
-// k_rt_pair<N>: one workgroup per stereo instance whose two channels multiply with the same IR spectra (the plug-in
-// feeds IR channel 0 to both, :485).  For each of the call's T blocks, in order:
+// k_rt_pair<N, NCH>: one workgroup per instance -- stereo, both channels multiplying with the same IR spectra (the plug-in feeds
+// IR channel 0 to both, :485; NCH = 2, "wave 2" below), or mono (NCH = 1: wave 1 takes the IR partition).  For each of the call's
+// T blocks, in order:
 //   * wave 2 re-derives ONE IR partition from the time-domain IR (the rolling refresh, :455-461): block j of the call
 //     refreshes partition (rf_part + j) mod P -- forward FFT next to the two audio FFTs of waves 0 and 1, spectrum into
 //     the H row for later launches and into LDS for this block;
@@ -18,13 +19,13 @@
 
 namespace irb {
 
-template <int N>
+template <int N, int NCH>
 struct LdsRt {
     static constexpr int M = N / 2;
     float2 tw[TwLds<N>::SIZE];
-    float2 buf[3][M];                                  // FFT work buffers: audio channel 0, channel 1, the IR partition
+    float2 buf[NCH + 1][M];                            // FFT work buffers: the audio channels, then the IR partition
     float2 hnew[M];                                    // packed spectrum of the partition refreshed with this block
-    float2 scratch[2][MacGeom<N>::STRIPES * M];        // new audio spectra, then the stripe partials
+    float2 scratch[NCH][MacGeom<N>::STRIPES * M];      // new audio spectra, then the stripe partials
 };
 
 // one sample the host may have stored through the BAR while a resident kernel was already running: system scope, past
@@ -43,33 +44,36 @@ __device__ __forceinline__ void rt_load_x(BlockIo<N> &io, const float *__restric
     for (int i = 0; i < BlockIo<N>::XL; i++) io.x[i] = ld_sample<SYS>(xin + min(lane + i * kWave, B - 1));
 }
 
-// T blocks of one stereo instance (workgroup blockIdx.x), block j refreshing partition (rf_part + j) mod np first; the
-// twiddle table is in lds.tw (staged by the caller, covered by the first barrier here)
-template <int N, bool SYS>
-__device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int T, int head0, int rf_part)
+// T blocks of one instance (workgroup blockIdx.x) with NCH = 1 or 2 audio channels that multiply with the same IR spectra, block j
+// refreshing partition (rf_part + j) mod np first; waves 0 .. NCH-1 own the audio channels' transforms, wave NCH the IR partition's;
+// the twiddle table is in lds.tw (staged by the caller, covered by the first barrier here)
+template <int N, bool SYS, int NCH>
+__device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N, NCH> &lds, int T, int head0, int rf_part)
 {
     using G = MacGeom<N>;
     constexpr int M = N / 2, U = 4;
-    const int s0 = 2 * blockIdx.x;
+    const int s0 = NCH * blockIdx.x;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int2 si = a.stream_info[s0];
     const int set = si.x, np = si.y;
     float2 *Hs = const_cast<float2 *>(a.H) + (size_t) set * a.P * M;
     const float4 *H4 = reinterpret_cast<const float4 *>(Hs);
-    float2 *Xs[2] = {a.X + (size_t) s0 * a.R * M, a.X + (size_t) (s0 + 1) * a.R * M};
-    const float4 *X4[2] = {reinterpret_cast<const float4 *>(Xs[0]), reinterpret_cast<const float4 *>(Xs[1])};
+    float2 *Xs[NCH];
+    const float4 *X4[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) { Xs[ch] = a.X + (size_t) (s0 + ch) * a.R * M; X4[ch] = reinterpret_cast<const float4 *>(Xs[ch]); }
     const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
     const float4 *hnew4 = reinterpret_cast<const float4 *>(lds.hnew);
 
-    // samples of the first block + the saved overlaps (waves 0, 1), of the first IR partition (wave 2).  Later blocks' samples
+    // samples of the first block + the saved overlaps (audio waves), of the first IR partition (wave NCH).  Later blocks' samples
     // are asked for one block ahead (below); the overlap stays in registers.
     BlockIo<N> io;
-    if (wave < 2) {
+    if (wave < NCH) {
         rt_load_x<N, SYS>(io, a.in + (size_t) (s0 + wave) * a.in_stride, a.B, lane);
         const float *ov = a.ovl + (size_t) (s0 + wave) * a.B;
 #pragma unroll
         for (int i = 0; i < BlockIo<N>::XL; i++) io.ov[i] = ov[min(lane + i * kWave, a.B - 1)];
-    } else if (wave == 2) {
+    } else if (wave == NCH) {
         rt_load_x<N, SYS>(io, a.rf_src + (size_t) (np > 0 ? rf_part % np : 0) * a.B, a.B, lane);
     }
 
@@ -80,21 +84,25 @@ __device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int 
         // the refreshed partition pairs with
         int slot_r = head - rp;
         if (slot_r < 0) slot_r += a.R;
-        float4 h0[G::CPT], xr0[G::CPT], xr1[G::CPT];
+        float4 h0[G::CPT], xr[NCH][G::CPT];
 #pragma unroll
         for (int c = 0; c < G::CPT; c++) {
             h0[c] = H4[col + c * G::LW];
-            xr0[c] = X4[0][(size_t) slot_r * G::L + col + c * G::LW];
-            xr1[c] = X4[1][(size_t) slot_r * G::L + col + c * G::LW];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) xr[ch][c] = X4[ch][(size_t) slot_r * G::L + col + c * G::LW];
         }
 
         // older partitions 1 .. np-1 except the one being refreshed (its H row is rewritten by wave 2 in this block)
-        float4 acc[2][G::CPT];
-        float2 dc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+        float4 acc[NCH][G::CPT];
+        float2 dc[NCH];
 #pragma unroll
-        for (int c = 0; c < G::CPT; c++) { acc[0][c] = make_float4(0.f, 0.f, 0.f, 0.f); acc[1][c] = acc[0][c]; }
+        for (int ch = 0; ch < NCH; ch++) {
+            dc[ch] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < G::CPT; c++) acc[ch][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         for (int k = 1 + stripe; k < np; k += U * G::STRIPES) {
-            float4 h[U][G::CPT], x0[U][G::CPT], x1[U][G::CPT];
+            float4 h[U][G::CPT], x[NCH][U][G::CPT];
 #pragma unroll
             for (int u = 0; u < U; u++) {              // clamped, never predicated: all loads of the group in flight together
                 const int kk = min(k + u * G::STRIPES, np - 1);
@@ -103,8 +111,8 @@ __device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int 
 #pragma unroll
                 for (int c = 0; c < G::CPT; c++) {
                     h[u][c] = H4[(size_t) kk * G::L + col + c * G::LW];
-                    x0[u][c] = X4[0][(size_t) slot * G::L + col + c * G::LW];
-                    x1[u][c] = X4[1][(size_t) slot * G::L + col + c * G::LW];
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) x[ch][u][c] = X4[ch][(size_t) slot * G::L + col + c * G::LW];
                 }
             }
 #pragma unroll
@@ -113,29 +121,28 @@ __device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int 
                 const bool live = kk < np && kk != rp;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int c = 0; c < G::CPT; c++) {
-                    cmac_pair(acc[0][c], dc[0], live ? x0[u][c] : z, h[u][c], c == 0);
-                    cmac_pair(acc[1][c], dc[1], live ? x1[u][c] : z, h[u][c], c == 0);
-                }
+                for (int c = 0; c < G::CPT; c++)
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) cmac_pair(acc[ch][c], dc[ch], live ? x[ch][u][c] : z, h[u][c], c == 0);
             }
         }
 
-        if (wave < 3) io.block_to_lds(lds.buf[wave], a.B, lane);
+        if (wave <= NCH) io.block_to_lds(lds.buf[wave], a.B, lane);
         if (j + 1 < T) {                               // the next block's samples land while this block is transformed
-            if (wave < 2) rt_load_x<N, SYS>(io, a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) (j + 1) * a.B, a.B, lane);
-            else if (wave == 2) rt_load_x<N, SYS>(io, a.rf_src + (size_t) (np > 0 ? (rf_part + j + 1) % np : 0) * a.B, a.B, lane);
+            if (wave < NCH) rt_load_x<N, SYS>(io, a.in + (size_t) (s0 + wave) * a.in_stride + (size_t) (j + 1) * a.B, a.B, lane);
+            else if (wave == NCH) rt_load_x<N, SYS>(io, a.rf_src + (size_t) (np > 0 ? (rf_part + j + 1) % np : 0) * a.B, a.B, lane);
         }
         // barriers inside a block order LDS traffic only (lds_barrier: no vmcnt drain), so those loads stay in flight
         lds_barrier();
-        if (wave < 2) {                                // new audio blocks: FFT, spectrum to LDS (partition 0) and into the ring
+        if (wave < NCH) {                              // new audio blocks: FFT, spectrum to LDS (partition 0) and into the ring
             wave_fft<M, false>(lds.buf[wave], lds.tw, lane);
-            float2 *ring = Xs[wave] + (size_t) head * M;
+            float2 *ring = a.X + ((size_t) (s0 + wave) * a.R + head) * M;
             float2 *sc = lds.scratch[wave];
             wave_split_forward<M>(lds.buf[wave], lds.tw, lane, [&](int b, float2 v) { sc[b] = v; ring[b] = v; });
-        } else if (wave == 2 && np > 0) {              // the refreshed IR partition: spectrum to LDS and into its H row
-            wave_fft<M, false>(lds.buf[2], lds.tw, lane);
+        } else if (wave == NCH && np > 0) {            // the refreshed IR partition: spectrum to LDS and into its H row
+            wave_fft<M, false>(lds.buf[NCH], lds.tw, lane);
             float2 *row = Hs + (size_t) rp * M;
-            wave_split_forward<M>(lds.buf[2], lds.tw, lane, [&](int b, float2 v) { lds.hnew[b] = v; row[b] = v; });
+            wave_split_forward<M>(lds.buf[NCH], lds.tw, lane, [&](int b, float2 v) { lds.hnew[b] = v; row[b] = v; });
         }
         lds_barrier();
         if (np > 0 && threadIdx.x < G::LW) {
@@ -143,18 +150,17 @@ __device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int 
             for (int c = 0; c < G::CPT; c++) {
                 const float4 hn = hnew4[col + c * G::LW];
                 const float4 hp0 = rp == 0 ? hn : h0[c];
-                cmac_pair(acc[0][c], dc[0], reinterpret_cast<const float4 *>(lds.scratch[0])[col + c * G::LW], hp0, c == 0);
-                cmac_pair(acc[1][c], dc[1], reinterpret_cast<const float4 *>(lds.scratch[1])[col + c * G::LW], hp0, c == 0);
-                if (rp != 0) {
-                    cmac_pair(acc[0][c], dc[0], xr0[c], hn, c == 0);
-                    cmac_pair(acc[1][c], dc[1], xr1[c], hn, c == 0);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    cmac_pair(acc[ch][c], dc[ch], reinterpret_cast<const float4 *>(lds.scratch[ch])[col + c * G::LW], hp0, c == 0);
+                    if (rp != 0) cmac_pair(acc[ch][c], dc[ch], xr[ch][c], hn, c == 0);
                 }
             }
         }
         lds_barrier();
-        reduce_stripes<N, true>(acc[0], dc[0], lds.scratch[0], lds.buf[0]);
-        reduce_stripes<N, true>(acc[1], dc[1], lds.scratch[1], lds.buf[1]);
-        if (wave < 2) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) reduce_stripes<N, true>(acc[ch], dc[ch], lds.scratch[ch], lds.buf[ch]);
+        if (wave < NCH) {
             wave_split_inverse<M>(lds.buf[wave], lds.tw, lane);
             wave_fft<M, true>(lds.buf[wave], lds.tw, lane);
             overlap_add_keep<N>(io, lds.buf[wave], a.B, a.ovl + (size_t) (s0 + wave) * a.B,
@@ -166,12 +172,12 @@ __device__ __forceinline__ void rt_blocks(const StepArgs &a, LdsRt<N> &lds, int 
     }
 }
 
-template <int N>
+template <int N, int NCH = 2>
 __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
 {
-    __shared__ LdsRt<N> lds;
+    __shared__ LdsRt<N, NCH> lds;
     stage_twiddles<N>(a.tw, lds.tw);                   // once for every block of the call (first barrier of rt_blocks covers it)
-    rt_blocks<N, false>(a, lds, a.T, a.head, a.rf_part);
+    rt_blocks<N, false, NCH>(a, lds, a.T, a.head, a.rf_part);
     if (a.done != nullptr && threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the output blocks reach host memory before the word
         __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -197,11 +203,11 @@ struct RtMailbox {
     unsigned pad[11];
 };
 
-template <int N>
+template <int N, int NCH = 2>
 __global__ __launch_bounds__(kThreads) void k_rt_server(StepArgs a, const RtMailbox *mb, unsigned *exited, unsigned gen,
                                                          unsigned first_seq, unsigned idle_ticks, unsigned life_ticks)
 {
-    __shared__ LdsRt<N> lds;
+    __shared__ LdsRt<N, NCH> lds;
     __shared__ int l_cmd[4];
     stage_twiddles<N>(a.tw, lds.tw);
     const unsigned long long born = __builtin_amdgcn_s_memrealtime();
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void k_rt_server(StepArgs a, const RtMail
         const int cmd = l_cmd[0], T = l_cmd[1], part = l_cmd[2], head = l_cmd[3];
         __syncthreads();                               // l_cmd may be rewritten by thread 0 as soon as it polls again
         if (!cmd) break;
-        rt_blocks<N, true>(a, lds, T, head, part);     // ends with a barrier behind every wave's drained stores
+        rt_blocks<N, true, NCH>(a, lds, T, head, part);   // ends with a barrier behind every wave's drained stores
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(a.done, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

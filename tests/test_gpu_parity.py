@@ -200,10 +200,10 @@ def test_rt_one_launch_callback_matches_two_launch_path_and_oracle(monkeypatch, 
     assert counts[1][0] >= 2 * blocks_per_cb - 0.05                                  # the A/B arm: refresh + step per block
 
 
-@pytest.mark.parametrize("case", [(2, 2, 128, 1024, 3), (1, 1, 256, 2048, 2), (1, 2, 256, 96000, 2), (1, 2, 2048, 8192, 1)],
+@pytest.mark.parametrize("case", [(2, 2, 128, 1024, 3), (3, 1, 256, 2048, 2), (1, 2, 256, 96000, 2), (1, 2, 2048, 8192, 1)],
                          ids=lambda c: "I%d_C%d_B%d_Lh%d_nb%d" % c)
 def test_process_refresh_on_engine_shapes_without_the_rt_kernel(case):
-    """irb_fdl_process_refresh on shapes that do not qualify for the one-launch kernel (several instances, mono, a long IR
+    """irb_fdl_process_refresh on shapes that do not qualify for the one-launch kernel (several instances, a long IR
     ring on the column-sliced path, B = 2048): refresh and step launches enqueued per block, one wait -- the same samples
     as irb_fdl_set_ir_partition + irb_fdl_process block by block."""
     I, C, B, Lh, nb = case
@@ -225,20 +225,21 @@ def test_process_refresh_on_engine_shapes_without_the_rt_kernel(case):
     assert np.array_equal(ya, yb) and np.abs(ya[(I - 1) * C:]).max() > 0
 
 
+@pytest.mark.parametrize("C", [2, 1], ids=["stereo", "mono"])
 @pytest.mark.parametrize("B,P,nb,first", [(64, 5, 3, 2), (128, 8, 2, 0), (256, 3, 4, 1), (512, 6, 2, 5), (32, 9, 1, 4)],
                          ids=lambda v: str(v))
-def test_rt_kernel_block_sizes_against_float64_model(B, P, nb, first):
-    """k_rt_pair<N> for N = 64 ... 1024 (the plug-in adapter only ever builds N = 512): one stereo instance, calls of nb blocks,
+def test_rt_kernel_block_sizes_against_float64_model(B, P, nb, first, C):
+    """k_rt_pair<N, channels> for N = 64 ... 1024 (the plug-in adapter only ever builds N = 512): one stereo or mono instance, calls of nb blocks,
     partition (first + j) mod P re-derived before block j -- against a float64 model written from the definition: block t sees
     exactly the partitions refreshed so far, y_t = sum_k x_(t-k) * h_k over those k (Source/PluginProcessor.cpp:455-501).
     The same calls through the refresh + step launches (IRB_FDL_NO_RT_KERNEL) must agree to rounding."""
     n_calls = 2 * P // nb + 3
     T = n_calls * nb
-    x = _streams(1, 2, T * B, 9400)
+    x = _streams(1, C, T * B, 9400)
     h = decaying_ir(9450, P * B)
     outs = []
     for extra in (0, _lib.NO_RT_KERNEL):
-        with FdlEngine(1, 2, B, P * B, max_blocks_per_call=nb, flags=_lib.HOST_IO | _lib.STEPWISE | extra) as eng:
+        with FdlEngine(1, C, B, P * B, max_blocks_per_call=nb, flags=_lib.HOST_IO | _lib.STEPWISE | extra) as eng:
             part, ys = first, []
             for k in range(n_calls):
                 ys.append(eng.process_refresh(x[:, k * nb * B:(k + 1) * nb * B], h, part))
@@ -251,17 +252,60 @@ def test_rt_kernel_block_sizes_against_float64_model(B, P, nb, first):
     avail_from = {}
     for t in range(T):
         avail_from.setdefault((first + t) % P, t)
-    ref = np.zeros((2, (T + 1) * B))
+    ref = np.zeros((C, (T + 1) * B))
     hk = [h[k * B:(k + 1) * B].astype(np.float64) for k in range(P)]
-    for c in range(2):
+    for c in range(C):
         xc = x[c].astype(np.float64)
         for t in range(T):
             for k in range(P):
                 if k in avail_from and avail_from[k] <= t and t - k >= 0:
                     seg = np.convolve(xc[(t - k) * B:(t - k + 1) * B], hk[k])          # 2B-1 samples starting at block t
                     ref[c, t * B:t * B + 2 * B - 1] += seg
-    for c in range(2):
+    for c in range(C):
         assert rel_rms(outs[0][c], ref[c, :T * B]) < RMS_TOL
+
+
+@pytest.mark.parametrize("host_block", [100, 256, 512])
+def test_rt_mono_plugin_callback_on_every_path(monkeypatch, host_block):
+    """A mono plug-in instance (getTotalNumInputChannels() == 1, Source/PluginProcessor.cpp:485 with one channel): the resident
+    server and the one-launch callback (k_rt_server / k_rt_pair with one audio wave + the IR wave) give the same samples bit for
+    bit, agree with the refresh + step launches to rounding and with the restated processBlock within the parity tolerance."""
+    irs = [decaying_ir(7, 8 * 256), decaying_ir(8, 8 * 256)[::-1].copy()]
+    n_cb = max(24, 256 * 30 // host_block)
+    x = white_noise(47, n_cb * host_block)[None, :].copy()
+    outs, per_cb = {}, {}
+    for mode, env in (("resident", {"IRB_RT_RESIDENT": "1", "IRB_RT_ONE_LAUNCH": "1"}), ("one_launch", {"IRB_RT_RESIDENT": "0", "IRB_RT_ONE_LAUNCH": "1"}),
+                      ("launch_pairs", {"IRB_RT_RESIDENT": "0", "IRB_RT_ONE_LAUNCH": "0"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        gpu = RtConvolver(1, 256, 2048)
+        gpu.prepareToPlay(host_block)
+        ref = oracle.RtProcessor(1, 256, 2048)
+        ref.prepare_to_play(host_block)
+        y, yr = np.empty_like(x), np.empty_like(x)
+        for k in range(n_cb):
+            if k in (3, n_cb // 2):
+                gpu.setIR(irs[k == 3])
+                ref.set_ir(irs[k == 3])
+            a = x[:, k * host_block:(k + 1) * host_block].copy()           # (a one-row slice is contiguous: ascontiguousarray would alias x)
+            b = a.copy()
+            gpu.processBlock(a)
+            y[:, k * host_block:(k + 1) * host_block] = a
+            if host_block <= 256:
+                ref.process_block(b)
+                yr[:, k * host_block:(k + 1) * host_block] = b
+            if k == 9:
+                c0 = gpu.counters()
+        c1 = gpu.counters()
+        per_cb[mode] = (c1[1] - c0[1]) / (c1[0] - c0[0])
+        if host_block <= 256:
+            assert rel_rms(y[0], yr[0]) < RMS_TOL
+        outs[mode] = y
+        gpu.close()
+    assert np.array_equal(outs["resident"], outs["one_launch"]) and np.abs(outs["resident"]).max() > 0
+    assert rel_rms(outs["one_launch"], outs["launch_pairs"]) < 2e-6
+    work = min(1.0, host_block / 256)
+    assert per_cb["resident"] < 0.1 * work and per_cb["one_launch"] <= work + 0.05 and per_cb["launch_pairs"] >= 2 * host_block / 256 - 0.05
 
 
 @pytest.mark.parametrize("idle_us,life_ms", [(20000, 1000), (30, 1000), (20000, 1)], ids=["steady", "idle_exits", "lifetime_exits"])
