@@ -56,6 +56,9 @@ struct irb_fdl {
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
     int tiled_kernel = 1;                    // time-tiled MAC: 1 k_cmac_tiled_pk (16 outputs x 8 partitions per step), 0 round 2's k_cmac_tiled<N,8> (IRB_TILED_KERNEL: A/B, tests)
     int tileTT = 16;                         // outputs per time tile of that kernel
+    int mfma_min_T = 512;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
+    int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
+    int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
@@ -243,6 +246,30 @@ int tiled_splits(const irb_fdl *h, int T)
     return std::max(1, std::min(by_work, by_chip));
 }
 
+// long calls: the Toeplitz-block MAC on the matrix cores (fdl_mfma.hpp)
+bool use_mfma(const irb_fdl *h, int T)
+{
+    return h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
+}
+
+// k_cmac_mfma keeps two stage images in LDS (117 KiB): beyond the 64 KiB a kernel gets without asking
+int mfma_prepare(const irb_fdl *h)
+{
+    FOR_N(h->N, HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&irb::k_cmac_mfma<NN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) irb::kMfmaLds)));
+    return IRB_OK;
+}
+
+// its partition splits: whole multiples only while the tiles x bin groups leave at least half of the CUs without a workgroup (a
+// split adds a partial spectrum per output; 240 workgroups on 256 CUs are faster unsplit: profiles/r03_mfma_ab.txt), every split
+// at least one LDS stage of chunks
+int mfma_splits(const irb_fdl *h, int T)
+{
+    const long wgs = (long) h->S * ((T + irb::kMfmaTile - 1) / irb::kMfmaTile) * (h->M / irb::kMfmaBins);
+    const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);
+    const int by_chip = (int) std::max<long>(1, h->mfma_wgs / wgs);
+    return std::max(1, std::min(by_work, by_chip));
+}
+
 irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long stride)
 {
     irb::StepArgs a;
@@ -342,9 +369,11 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
     // one complex bin per lane, 16 outputs per tile: fewer bytes per FMA.  Pays when the rows come from HBM (working
     // set beyond the Infinity Cache) and the call is long enough; cache-resident calls are faster with k_cmac_tiled
-    const bool one_bin = h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
+    const bool mfma = use_mfma(h, T);
+    const bool one_bin = !mfma && h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
-    if (one_bin) a.nq = a.splits * stripes1;
+    if (mfma) { a.splits = mfma_splits(h, T); a.nq = a.splits; }
+    else if (one_bin) a.nq = a.splits * stripes1;
     else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
     if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
     const int tt = tile_outputs(h, T);
@@ -354,7 +383,11 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
     // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
     const bool nt1 = h->nt && ntiles == 1;
-    if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    if (mfma) {
+        const dim3 grid(h->S * ((T + irb::kMfmaTile - 1) / irb::kMfmaTile) * a.splits * (h->M / irb::kMfmaBins));
+        FOR_N(h->N, irb::k_cmac_mfma<NN><<<grid, dim3(irb::kMfmaThreads), irb::kMfmaLds, h->stream>>>(a));
+    }
+    else if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (h->tiled_kernel == 0) {
         if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
         else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
@@ -532,6 +565,9 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
     if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
     h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
+    h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 512));
+    h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
+    h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
     // resident workgroups of the MAC kernel: 256 CUs x waves per SIMD its registers allow (2 / 2 / 3 / 4); round 2: 768 as a floor
     const int slots[2] = {768, 512};
     h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", slots[h->tiled_kernel]));
@@ -548,13 +584,17 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc != IRB_OK) break;
         const size_t SM = (size_t) h->S * h->M;
+        if (!h->stepwise && use_mfma(h, h->Tmax) && !guard(mfma_prepare(h))) break;
         if (!guard(dev_alloc(h, &h->d_H, SM * h->Ppad + (size_t) 8 * h->M))) break;     // + spare rows: the tiled MAC's last prefetch reads past the last set
         if (!guard(dev_alloc(h, &h->d_X, SM * h->R))) break;
         if (!guard(dev_alloc(h, &h->d_tw, (size_t) h->N))) break;
         {
             const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
             size_t rows = (size_t) h->S * std::max(h->splits, 1);
-            for (int T = 2; T <= h->Tmax && !h->stepwise; T++) rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
+            for (int T = 2; T <= h->Tmax && !h->stepwise; T++) {
+                rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
+                if (use_mfma(h, T)) rows = std::max(rows, (size_t) h->S * T * mfma_splits(h, T));
+            }
             h->part_rows = rows;
         }
         if (!guard(dev_alloc(h, &h->d_part, h->part_rows * h->M))) break;

@@ -1350,4 +1350,5 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *
 }  // namespace irb
 
 #include "fdl_tiled_pk.hpp"
+#include "fdl_mfma.hpp"
 #include "fdl_rt_kernel.hpp"

@@ -700,6 +700,62 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
 
 
+@pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 32, 19200, 1100), (3, 1, 64, 900, 50),
+                                        (1, 2, 1024, 40000, 17), (1, 1, 2048, 9000, 5), (1, 2, 16, 700, 1300), (2, 1, 256, 96000, 40),
+                                        (1, 1, 64, 64 * 31, 70), (1, 1, 64, 64 * 33, 70)],
+                         ids=lambda v: str(v))
+def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
+    """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_32x32x2_f32; the default for calls of
+    >= 512 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
+    that end inside the first 1024-block tile or span two, partition counts around the 32-tap chunk edges, several partition
+    splits (P = 600: two LDS stages per split), packed bin 0, stereo IRs, history across calls (one signal as two calls)."""
+    x = _streams(I, C, T * B, 955)
+    irs = [np.stack([decaying_ir(960 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    outs = []
+    for min_t in ("2", "0"):
+        monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", min_t)
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            y = eng.process(x)
+            eng.reset()
+            cut = (T // 3) * B
+            y2 = np.concatenate([eng.process(x[:, :cut]), eng.process(x[:, cut:])], axis=1)
+        assert rel_rms(y, y2) < 2e-6
+        outs.append(y)
+    assert rel_rms(outs[0], outs[1]) < 2e-6 and not np.array_equal(outs[0], outs[1])      # really another kernel
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
+
+
+@pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513)], ids=lambda v: str(v))
+def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B, Lh, T):
+    """No tuning variable set: a call of >= 512 blocks multiplies on the matrix cores (another summation order than the packed-FMA
+    kernel's, so the two outputs differ in the last bits), shorter calls of the same engine do not; both against the oracle, and
+    one signal fed as a long and a short call continues seamlessly (the FDL history is shared by both kernels)."""
+    for k in ("IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS"):
+        monkeypatch.delenv(k, raising=False)
+    x = _streams(I, C, (T + 40) * B, 975)
+    irs = [np.stack([decaying_ir(980 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", "0")
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            for i in range(I):
+                eng.set_ir(i, irs[i])
+            outs.append(np.concatenate([eng.process(x[:, :T * B]), eng.process(x[:, T * B:])], axis=1))
+    assert rel_rms(outs[0], outs[1]) < 2e-6
+    assert not np.array_equal(outs[0][:, :T * B], outs[1][:, :T * B])          # the long call: two different kernels
+    assert np.array_equal(outs[0][:, T * B:] != 0, outs[1][:, T * B:] != 0)
+    for i in range(I):
+        ref, _ = oracle.convolve_periodic(x[i * C:(i + 1) * C], irs[i], B)
+        for c in range(C):
+            assert rel_rms(outs[0][i * C + c], ref[c, :(T + 40) * B]) < RMS_TOL
+
+
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 512, 6000, 16), (3, 1, 64, 900, 50),
                                         (1, 2, 1024, 9000, 17), (1, 1, 2048, 9000, 5)])
 def test_packed_fma_tiled_kernel(monkeypatch, I, C, B, Lh, T):

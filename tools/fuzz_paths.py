@@ -18,7 +18,11 @@ while time.time() - t0 < budget:
     cap = int(rng.integers(1, 40)) * B + int(rng.integers(0, B))
     Lh = int(rng.integers(1, cap + 1))
     T = int(rng.integers(1, 14))
-    tmax = int(rng.choice([1, 1, 1, 3, 8, 20, 40]))
+    tmax = int(rng.choice([1, 1, 1, 3, 8, 20, 40, 300]))
+    if tmax == 300:                                                # calls that span two tiles of the matrix-core MAC: keep the case small
+        I, B = min(I, 3), min(B, 128)
+        cap = int(rng.integers(1, 40)) * B + int(rng.integers(0, B))
+        Lh = int(rng.integers(1, cap + 1))
     T = int(rng.integers(1, 14)) if tmax <= 8 else int(rng.integers(tmax // 2, 2 * tmax + 3))
     flags = int(rng.choice([0, _lib.FORCE_COLS, _lib.FORCE_COLS, _lib.FORCE_FUSED, _lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH]))
     env = {}
@@ -26,7 +30,10 @@ while time.time() - t0 < budget:
         env = {"IRB_COLW": str(rng.choice([4, 16, 64])), "IRB_COLS_HANDOFF": str(rng.choice([0, 1, 2])), "IRB_PSPLITS": str(rng.integers(1, 17))}
     env["IRB_TILED_KERNEL"] = str(rng.choice([0, 1, 1]))        # round 2's tiled MAC / the packed-FMA one
     env["IRB_FUSED_U"] = str(rng.choice([2, 4]))
-    for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS", "IRB_TILED_KERNEL", "IRB_FUSED_U"):
+    env["IRB_TILED_MFMA_MIN_T"] = str(rng.choice([0, 2, 2]))    # off / the matrix-core tiled MAC for every call of >= 2 blocks
+    env["IRB_TILED_MFMA_WGS"] = str(rng.choice([16, 256, 2048]))
+    env["IRB_TILED_MFMA_MIN_CHUNKS"] = str(rng.choice([1, 6]))
+    for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS", "IRB_TILED_KERNEL", "IRB_FUSED_U", "IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ir_ch = int(rng.integers(1, 3))
