@@ -225,7 +225,7 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
                 ent["algorithmic_bytes_model"] = "12*P*N + 32*B per instance-step (H row shared by both channels)"
             ent["algorithmic_GBps"] = round(alg / ms / 1e6, 1)
             ent["frac_of_hbm_peak"] = round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)
-        else:           # time-tiled: rows are reused in registers, the call is fp32-VALU bound: flops of the complex MAC
+        else:           # time-tiled: rows are reused on chip, the call is bound by fp32 multiply-adds (vector ALU or matrix cores: the same peak)
             flops = 8.0 * e.info.partitions * (e.info.fft_len // 2) * T * I * C
             ent["fp32_flops"] = flops
             ent["TFLOPs"] = round(flops / ms / 1e9, 2)
@@ -234,15 +234,17 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
             min_bytes = float(I * C) * (2 * e.info.partitions + T) * e.info.fft_len * 4.0
             ent["min_traffic_GBps"] = round(min_bytes / ms / 1e6, 1)
             ent["frac_of_hbm_peak_min_traffic"] = round(min_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
-            ent["roofline_note"] = ("whole call (forward FFTs + MAC + inverse FFTs / overlap-add) against the fp32 vector peak; "
-                                    "MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, T blocks.  min_traffic: H and the "
-                                    "FDL window read once per call -- the binding side of HBM-sized batches with few blocks per call "
-                                    "(cache-resident calls are VALU-bound and leave it far below 1)")
+            ent["mac_kernel"] = ("k_cmac_mfma (v_mfma_f32_16x16x4_f32: Toeplitz blocks along the time axis)" if T >= 512 and "IRB_TILED_MFMA_MIN_T" not in os.environ
+                                 else "k_cmac_tiled_pk (v_pk_fma_f32)")
+            ent["roofline_note"] = ("whole call (forward FFTs + MAC + inverse FFTs / overlap-add) against the fp32 peak (157.3 TFLOP/s, vector ALU "
+                                    "and exact-fp32 matrix instructions alike); MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, "
+                                    "T blocks.  min_traffic: H and the FDL window read once per call -- the binding side of HBM-sized batches "
+                                    "with few blocks per call (cache-resident calls are compute-bound and leave it far below 1)")
         res[name] = ent
         e.close()
 
     run("configs[1]_offline_one_stream", 1, 1, 256, 96000, 3750, 200,
-        "ONE mono stream, whole 960000-sample signal in one call (time-tiled MAC); cache-resident, compute-bound")
+        "ONE mono stream, whole 960000-sample signal in one call (time-tiled MAC on the matrix cores); cache-resident, compute-bound")
     run("configs[1]_x2048_8_blocks_per_call", 2048, 1, 256, 96000, 8, 10,
         "2048 instances, 8 blocks per call: H and FDL rows are read once per 8 outputs")
     run("configs[2]_stereo_10s_ir_streaming", 1, 2, 128, 480000, 1, 400,

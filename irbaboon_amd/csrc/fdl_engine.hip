@@ -249,10 +249,12 @@ int tiled_splits(const irb_fdl *h, int T)
 // long calls: the Toeplitz-block MAC on the matrix cores (fdl_mfma.hpp)
 bool use_mfma(const irb_fdl *h, int T)
 {
-    return h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
+    // (its buffer descriptors address a stream's FDL ring and an IR set with 31-bit byte offsets)
+    const size_t row = (size_t) h->M * sizeof(float2);
+    return h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0 && (size_t) h->R * row < (1u << 31) && (size_t) h->Ppad * row < (1u << 31);
 }
 
-// k_cmac_mfma keeps two stage images in LDS (117 KiB): beyond the 64 KiB a kernel gets without asking
+// k_cmac_mfma keeps two stage images in LDS (141 KiB): beyond the 64 KiB a kernel gets without asking
 int mfma_prepare(const irb_fdl *h)
 {
     FOR_N(h->N, HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&irb::k_cmac_mfma<NN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) irb::kMfmaLds)));

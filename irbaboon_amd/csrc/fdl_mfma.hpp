@@ -18,7 +18,7 @@
 // MFMA measured, tools/mfma_stamps.hip), and two waves that meet at a barrier every stage still left it idle a quarter of the time.
 // The range of j is walked in stages of kMfmaJC chunks: the H taps and X rows a stage needs go global -> registers -> LDS
 // (rows of 128 B: every line is used whole; buffer loads with the row step in an SGPR: no vector instruction per load) into one
-// half of the LDS while the other half is multiplied -- one barrier per stage --, X folded
+// half of the LDS while the other half is multiplied -- one barrier per stage of 9 chunks; 141 KiB of LDS for both --, X folded
 // as [k / 2][row][k % 2] so that the operand read of a 32-lane group (ds_read_b64) is one contiguous 256 bytes = every bank once.  Per (chunk, bin) a wave reads 8
 // operands of 8 bytes from LDS -- one unit ahead, in registers: a wave that waits for a ds_read lets the matrix pipe run dry --
 // and issues 16 v_mfma_f32_16x16x4_f32 (512 cycles of matrix pipe).  The 256 x 16 results leave through LDS as whole 128-byte
@@ -39,7 +39,10 @@ constexpr int kMfmaTile = kMfmaSeg * kMfmaSeg;         // output blocks per work
 constexpr int kMfmaBins = 16;                          // bins per workgroup = waves per workgroup
 constexpr int kMfmaThreads = kMfmaBins * kWave;        // 1024
 constexpr int kMfmaSR = kMfmaThreads / kMfmaBins;      // FDL rows a staging pass covers: 64 = four X rows of 16 blocks
-constexpr int kMfmaJC = 6;                             // Toeplitz chunks per LDS stage
+#ifndef IRB_MFMA_JC
+#define IRB_MFMA_JC 9
+#endif
+constexpr int kMfmaJC = IRB_MFMA_JC;                   // Toeplitz chunks per LDS stage (tools/mfma_stamps.hip builds variants)
 constexpr int kMfmaNC = kMfmaJC + kMfmaSeg - 1;        // X rows (of 16 blocks) a stage needs
 constexpr int kMfmaNH = kMfmaJC + 2;                   // H chunks a stage needs (one before, up to one after)
 constexpr int kMfmaXI = (kMfmaNC + 3) / 4, kMfmaHI = (kMfmaNH + 3) / 4;     // staging passes

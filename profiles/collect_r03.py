@@ -99,7 +99,9 @@ def main():
                        "(k1 = k_cmac_tiled_pk, k0 = round 2's k_cmac_tiled); SQ_* in quad-cycles summed over waves, per launch",
                "counters_mean_per_launch": tiled}, open(os.path.join(HERE, "r03_tiled_mac_pmc.json"), "w"), indent=1)
     for src, dst in (("tiled_pmc_cfg2.txt", "r03_tiled_kernels_cfg2.txt"), ("tiled_pmc_cfg3.txt", "r03_tiled_kernels_cfg3.txt"), ("tiled_stamps.txt", "r03_tiled_stamps.txt"),
-                     ("valu_peak.txt", "r03_valu_peak.txt"), ("rt_ab.txt", "r03_rt_callback_ab.txt"), ("handoff_under_load.txt", "r03_handoff_under_load.txt")):
+                     ("valu_peak.txt", "r03_valu_peak.txt"), ("rt_ab.txt", "r03_rt_callback_ab.txt"), ("handoff_under_load.txt", "r03_handoff_under_load.txt"),
+                     ("mfma_trace.txt", "r03_mfma_kernel_trace.txt"), ("mfma_stamps.txt", "r03_mfma_stamps.txt"), ("mfma_pmc.txt", "r03_mfma_pmc.txt"),
+                     ("mfma_peak.txt", "r03_mfma_peak.txt"), ("mfma_ab.txt", "r03_mfma_ab.txt")):
         f = os.path.join(P, src)
         if os.path.exists(f):
             shutil.copy(f, os.path.join(HERE, dst))

@@ -64,7 +64,8 @@ def test_every_bench_kernel_is_launched_by_a_parity_test():
     rows = [l for l in lines[1:-1] if "irb::" in l]
     assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
     assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, 2" in l for l in rows)
-    assert any("k_rt_pair<512>" in l for l in rows) and any("k_cmac_tiled_pk<512, 16, 8, 2, false>" in l for l in rows)
+    assert any("k_rt_pair<512" in l for l in rows) and any("k_cmac_mfma<512>" in l for l in rows) and any("k_cmac_mfma<256>" in l for l in rows)
+    assert any("k_cmac_tiled_pk<512, 8, 4, 4" in l for l in rows)
     assert any("k_ifft_ola_run<512, 4>" in l for l in rows) and any("k_lfft_rows_split<1024, 4>" in l for l in rows)
 
 

@@ -23,10 +23,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/rt512_kt -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lfft_kt -- python3 $R/tools/perf_probe.py lfft 20 1 100 > $O/lfft_kt.log 2>&1
 cd $R
 echo "== time-tiled MAC: counters, stamps"
-./tools/tiled_profile.sh "256 96000 3750 1" 1 0 > $O/tiled_pmc_cfg2.txt 2>&1
-./tools/tiled_profile.sh "128 480000 2048 2" 1 > $O/tiled_pmc_cfg3.txt 2>&1
+IRB_TILED_MFMA_MIN_T=0 ./tools/tiled_profile.sh "256 96000 3750 1" 1 0 > $O/tiled_pmc_cfg2.txt 2>&1       # the vector kernels (calls of < 512 blocks; A/B arm of longer ones)
+IRB_TILED_MFMA_MIN_T=0 ./tools/tiled_profile.sh "128 480000 2048 2" 1 > $O/tiled_pmc_cfg3.txt 2>&1
 for a in "3750 2" "3750 1" "3750 4" "940 8" "7500 1"; do timeout -k 5 60 ./tools/tiled_stamps $a; done > $O/tiled_stamps.txt 2>&1
 ./tools/valu_peak > $O/valu_peak.txt 2>&1
+echo "== matrix-core tiled MAC: kernel trace of the offline calls, stamps, counters, instruction peak, A/B against the vector kernel"
+./tools/mfma_trace.sh "256 96000 3750 1 100" "128 480000 2048 2 50" "256 96000 1024 16 20" > $O/mfma_trace.txt 2>&1
+for a in "3750 1 375" "1024 4 375" "2048 2 3750"; do timeout -k 5 60 ./tools/mfma_stamps $a; done > $O/mfma_stamps.txt 2>&1
+./tools/mfma_pmc.sh "3750 1 375" > $O/mfma_pmc.txt 2>&1
+./tools/mfma_peak > $O/mfma_peak.txt 2>&1
+./tools/mfma_ab.sh; cp gpurun_out/mfma_ab.txt $O/mfma_ab.txt
 echo "== real-time callback A/B, hand-off soak"
 for hb in 64 256 512 1024; do python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 IRB_RT_BAR=0 python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 IRB_RT_ONE_LAUNCH=0 python3 tools/perf_probe.py rtc $hb 3000; done > $O/rt_ab.txt 2>&1
 timeout -k 10 300 python3 tools/handoff_under_load.py > $O/handoff_under_load.txt 2>&1; tail -2 $O/handoff_under_load.txt
