@@ -221,14 +221,24 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_cmac_mfma(StepArgs a)
 #endif
 #pragma unroll 1
     for (int st = 0; st < nst; st++) {
+        // (at raised priority: at equal priority the arbiter serves the oldest wave's MFMA stream first, the youngest waves took 16 000 cycles
+        // to get through these few dozen instructions and then multiplied alone at the end of the stage -- tools/mfma_stamps.hip ... waves)
+        __builtin_amdgcn_s_setprio(3);
         if (st + 1 < nst) put((st & 1) ^ 1);
         if (st + 2 < nst) fetch(stage_begin(st + 2), stage_begin(st + 3) - stage_begin(st + 2));
+        __builtin_amdgcn_s_setprio(0);
 #ifdef IRB_STAMPS
         const unsigned long long t_in = __builtin_amdgcn_s_memtime();
 #endif
         multiply_stage(stage_begin(st + 1) - stage_begin(st), st & 1);
 #ifdef IRB_STAMPS
-        t_mult += __builtin_amdgcn_s_memtime() - t_in;
+        const unsigned long long t_out = __builtin_amdgcn_s_memtime();
+        t_mult += t_out - t_in;
+        if (blockIdx.x == gridDim.x / 2 && lane == 0 && st < 4) {         // one workgroup's per-wave timeline, behind the per-workgroup records
+            unsigned long long *w = a.stamps + (size_t) gridDim.x * 16 + wave * 16 + st * 4;
+            w[0] = t_mark; w[1] = t_in; w[2] = t_out;
+            w[3] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_ID: SIMD in bits 5:4
+        }
 #endif
         __syncthreads();                                           // image st % 2 has been multiplied by everyone; image (st + 1) % 2 is complete
     }

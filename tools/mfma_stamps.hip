@@ -26,7 +26,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dX, (size_t) M * R * sizeof(float2)));
     CK(hipMalloc(&dpart, (size_t) T * splits * M * sizeof(float2)));
     CK(hipMalloc(&dinfo, sizeof(int2)));
-    CK(hipMalloc(&dst, (size_t) grid * 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&dst, (size_t) (grid + 16) * 16 * sizeof(unsigned long long)));
     {
         std::vector<float2> h((size_t) M * std::max(Ppad + 8, R));
         unsigned long long z = 12345;
@@ -40,13 +40,13 @@ int main(int argc, char **argv)
     std::memset(&a, 0, sizeof a);
     a.stamps = dst; a.H = dH; a.X = dX; a.stream_info = dinfo; a.part = dpart;
     a.B = B; a.P = Ppad; a.R = R; a.head = Ppad; a.splits = splits; a.T = T; a.nq = splits;
-    std::vector<unsigned long long> st((size_t) grid * 16);
+    std::vector<unsigned long long> st((size_t) (grid + 16) * 16);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&irb::k_cmac_mfma<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) irb::kMfmaLds));
     for (int it = 0; it < 6; it++) {
-        CK(hipMemset(dst, 0, (size_t) grid * 16 * sizeof(unsigned long long)));
+        CK(hipMemset(dst, 0, (size_t) (grid + 16) * 16 * sizeof(unsigned long long)));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         irb::k_cmac_mfma<N><<<dim3(grid), dim3(irb::kMfmaThreads), irb::kMfmaLds>>>(a);
@@ -88,5 +88,20 @@ int main(int argc, char **argv)
     std::printf("  stores (shader cycles):                p10 %.0f  p50 %.0f  p90 %.0f  max %.0f\n", pct(store, .1), pct(store, .5), pct(store, .9), pct(store, 1));
     std::printf("  shader clock (GHz):                    p10 %.2f  p50 %.2f  p90 %.2f\n", pct(clk, .1), pct(clk, .5), pct(clk, .9));
     std::printf("  distinct CUs used %zu, most workgroups on one CU %d\n", cu_iv.size(), maxper);
+    if (argc > 4) {                                   // one workgroup's waves, stage by stage: cycles after that stage's barrier at which a wave starts / ends its MFMA code
+        const unsigned long long *w = &st[(size_t) grid * 16];
+        for (int stg = 0; stg < 4; stg++) {
+            unsigned long long b = ~0ull;
+            for (int wv = 0; wv < 16; wv++) if (w[wv * 16 + stg * 4]) b = std::min(b, w[wv * 16 + stg * 4]);
+            if (b == ~0ull) continue;
+            std::printf("  stage %d of workgroup %d (wave: SIMD, MFMA code from .. to, cycles after the barrier):", stg, grid / 2);
+            for (int wv = 0; wv < 16; wv++) {
+                const unsigned long long *e = w + wv * 16 + stg * 4;
+                if (wv % 4 == 0) std::printf("\n   ");
+                std::printf(" w%-2d s%llu %5llu..%-6llu", wv, (e[3] >> 4) & 3, e[1] - b, e[2] - b);
+            }
+            std::printf("\n");
+        }
+    }
     return 0;
 }
