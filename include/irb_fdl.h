@@ -128,7 +128,11 @@ int  irb_fdl_reset(irb_fdl *h);
  * multiply-accumulate over partitions (fp/convolution.cpp:171-202; RT :480-501),
  * inverse FFT (:206; RT :504) and overlap-add (:209-213; RT :506-510).
  * in/out: host pointers, planar, one per stream (stream = instance*channels+ch),
- * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.     */
+ * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.
+ * Calls of several blocks multiply in tiles along the time axis (>= 512 blocks: on the
+ * matrix cores) whose zero padding meets neighbouring blocks: for finite samples the
+ * result is the reference's; an Inf or NaN sample can reach output blocks a tile's
+ * width (<= 255 blocks) outside the np blocks it reaches in the reference.          */
 int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
 
 /* Replaces: the body of the IRCAP_IDLE branch for the n_blocks complete blocks of one host callback
