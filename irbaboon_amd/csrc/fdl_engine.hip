@@ -251,7 +251,8 @@ bool use_mfma(const irb_fdl *h, int T)
 {
     // (its buffer descriptors address a stream's FDL ring and an IR set with 31-bit byte offsets)
     const size_t row = (size_t) h->M * sizeof(float2);
-    return h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0 && (size_t) h->R * row < (1u << 31) && (size_t) h->Ppad * row < (1u << 31);
+    // gfx950 only: 141 KiB of LDS per workgroup, descriptor word and instruction timings are that chip's
+    return h->is_gfx950 && h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0 && (size_t) h->R * row < (1u << 31) && (size_t) h->Ppad * row < (1u << 31);
 }
 
 // k_cmac_mfma keeps two stage images in LDS (141 KiB): beyond the 64 KiB a kernel gets without asking
