@@ -11,17 +11,18 @@
 // measured (tools/mfma_peak.hip, profiles/r03_mfma_peak.txt), sustain 0.89-0.97 of it from ONE wave per SIMD at 2.1-2.4 GHz, where
 // the packed-FMA kernel (fdl_tiled_pk.hpp) is issue-bound at 0.43 and pulls the clock to 1.7 GHz.
 //
-// A complex product is four real ones: Or = sum Xr Hr - sum Xi Hi (two accumulators, subtracted once), Oi += Xi Hr + Xr Hi (the packed bin 0 -- DC and Nyquist, two real
-// products -- takes the first of each only).  Workgroup = 16 neighbouring bins (one 128-byte line of every FDL / H / partial row)
-// x one tile of 16 segments (256 output blocks) x one range of j; 16 waves, one bin each (8 accumulator registers), four per SIMD:
-// ONE wave cannot keep the matrix pipe full (its operand reads and sign flips sit between its own MFMAs: 39-49 cycles per 32-cycle
-// MFMA measured, tools/mfma_stamps.hip), and two waves that meet at a barrier every stage still left it idle a quarter of the time.
+// A complex product is four real ones: Or = sum Xr Hr - sum Xi Hi (two accumulators, subtracted once: no sign flip in the loop),
+// Oi += Xi Hr + Xr Hi (the packed bin 0 -- DC and Nyquist, two real products -- takes the first of each only).  Workgroup = 16
+// neighbouring bins (one 128-byte line of every FDL / H / partial row) x one tile of 16 segments (256 output blocks) x one range
+// of j; 16 waves, one bin each (12 accumulator registers), four per SIMD: ONE wave cannot keep the matrix pipe full (its operand
+// reads and address updates sit between its own MFMAs: 39-49 cycles per 32-cycle MFMA measured, tools/mfma_stamps.hip), and two
+// waves that meet at a barrier every stage still left it idle a quarter of the time.
 // The range of j is walked in stages of kMfmaJC chunks: the H taps and X rows a stage needs go global -> registers -> LDS
 // (rows of 128 B: every line is used whole; buffer loads with the row step in an SGPR: no vector instruction per load) into one
 // half of the LDS while the other half is multiplied -- one barrier per stage of 9 chunks; 141 KiB of LDS for both --, X folded
-// as [k / 2][row][k % 2] so that the operand read of a 32-lane group (ds_read_b64) is one contiguous 256 bytes = every bank once.  Per (chunk, bin) a wave reads 8
-// operands of 8 bytes from LDS -- one unit ahead, in registers: a wave that waits for a ds_read lets the matrix pipe run dry --
-// and issues 16 v_mfma_f32_16x16x4_f32 (512 cycles of matrix pipe).  The 256 x 16 results leave through LDS as whole 128-byte
+// as [k / 2][row][k % 2] so that the operand read of a 32-lane group (ds_read_b64) is one contiguous 256 bytes = every bank
+// once.  Per chunk a wave reads 8 operands of 8 bytes from LDS -- half a chunk ahead, in registers: a wave that waits for a
+// ds_read lets the matrix pipe run dry -- and issues 16 v_mfma_f32_16x16x4_f32 (512 cycles of matrix pipe).  The 256 x 16 results leave through LDS as whole 128-byte
 // rows of part[s][t][split][M] (summed over splits by k_ifft_ola_run, like those of k_cmac_tiled_pk).
 //
 // Not bit-identical to the vector kernels (another summation order); parity with the oracle at the same tolerance (tests).
