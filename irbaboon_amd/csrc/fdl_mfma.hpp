@@ -26,6 +26,8 @@
 // rows of part[s][t][split][M] (summed over splits by k_ifft_ola_run, like those of k_cmac_tiled_pk).
 //
 // Not bit-identical to the vector kernels (another summation order); parity with the oracle at the same tolerance (tests).
+// The index arithmetic (tiles, splits, stage windows, LDS images, operand positions) is restated in tests/kernel_model.py
+// (mfma_time_axis) and checked against the direct sum on a machine without a GPU.
 // Non-finite input: as with the zero rows that pad H to whole ring periods in fdl_tiled_pk.hpp, 0 * X products exist for X blocks
 // next to the ones an output really depends on (here: up to 255 blocks later / 31 blocks earlier), so an Inf or NaN sample
 // can spread further along the time axis than in the reference; finite input is unaffected.

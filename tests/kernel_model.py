@@ -209,3 +209,60 @@ def rows_split_layout(M1, M2, R):
                 mr = r if self_row else R - 1 - r
                 mc = ((M2 - k2) & (M2 - 1)) if (self_row and r == 0) else M2 - 1 - k2
                 yield g, r, row_of(r), k2, row_of(mr), mc
+
+
+# ---- csrc/fdl_mfma.hpp: the time axis of one bin as Toeplitz-block products ---------------------------------------
+MFMA_SEG, MFMA_JC = 16, 9
+MFMA_NC, MFMA_NH = MFMA_JC + MFMA_SEG - 1, MFMA_JC + 2
+
+
+def mfma_chunks(np_):
+    """chunks j = 0 .. J-1 of 16 partitions whose Toeplitz blocks M_j[k][i] = H[16 j + i - k] cover every m in [0, np)"""
+    return (np_ + MFMA_SEG - 2) // MFMA_SEG + 1 if np_ > 0 else 0
+
+
+def mfma_time_axis(X, H, T, splits=1):
+    """k_cmac_mfma for ONE bin: X[tau] for tau in (-np, T) (dict-like: callable tau -> complex, zero outside), H[m], m < np.
+    Walks tiles of 256 output blocks, partition splits and stages of MFMA_JC chunks exactly as the kernel does -- stage windows
+    (tau_lo, m_lo), the LDS images' index formulas, the operand positions of lane (n, kq) at (chunk j, k group g), the output
+    register map -- and returns [splits][T] partial sums (float64: this checks indices, not rounding)."""
+    np_ = len(H)
+    J = mfma_chunks(np_)
+    out = np.zeros((splits, T), np.complex128)
+    x_at = lambda tau: X(tau) if -np_ < tau < T else 0.0
+    h_at = lambda m: H[m] if 0 <= m < np_ else 0.0
+    for tile in range((T + 255) // 256):
+        s0 = tile * MFMA_SEG
+        for split in range(splits):
+            jb, je = J * split // splits, J * (split + 1) // splits
+            acc = np.zeros((MFMA_SEG, MFMA_SEG), np.complex128)          # O[n][i]
+            for ja in range(jb, je, MFMA_JC):
+                jc = min(MFMA_JC, je - ja)
+                tau_lo, m_lo = MFMA_SEG * (s0 - ja - jc + 1), MFMA_SEG * ja - MFMA_SEG
+                # the stage images: X as [k / 2][X row][k % 2], H as [m - m_lo]; staging thread srow -> k = srow % 16, row 4 it + srow / 16
+                lx = np.zeros(MFMA_SEG * MFMA_NC, np.complex128)
+                lh = np.zeros(MFMA_SEG * MFMA_NH, np.complex128)
+                for srow in range(64):
+                    sk, sc = srow % MFMA_SEG, srow // MFMA_SEG
+                    for it in range((MFMA_NC + 3) // 4):
+                        c = 4 * it + sc
+                        if c < MFMA_NC:
+                            ok = c < jc + MFMA_SEG - 1
+                            lx[((sk // 2) * MFMA_NC + sc) * 2 + sk % 2 + 8 * it] = x_at(tau_lo + srow + 64 * it) if ok else 0.0
+                    for it in range((MFMA_NH + 3) // 4):
+                        if 4 * it + sc < MFMA_NH:
+                            ok = 4 * it + sc < jc + 2
+                            lh[srow + 64 * it] = h_at(m_lo + srow + 64 * it) if ok else 0.0
+                # the multiply: lane (n, kq), chunk j, k group g
+                for j in range(jc):
+                    for g in range(4):
+                        for kq in range(4):
+                            xs = np.array([lx[((kq // 2) * MFMA_NC + n + jc - 1) * 2 + kq % 2 + (2 * g * MFMA_NC - j) * 2] for n in range(MFMA_SEG)])
+                            hs = np.array([lh[MFMA_SEG + i - kq + MFMA_SEG * j - 4 * g] for i in range(MFMA_SEG)])
+                            acc += np.outer(xs, hs)                       # one k of v_mfma_f32_16x16x4: O[n][i] += X(n, k) * H(k, i)
+            for n in range(MFMA_SEG):
+                for i in range(MFMA_SEG):
+                    t = 256 * tile + MFMA_SEG * n + i
+                    if t < T:
+                        out[split, t] = acc[n, i]
+    return out

@@ -54,3 +54,20 @@ def test_fused_split_row_pairing(M1, M2, R):
         seen[e] += 1
         assert mk1 + M1 * mk2 == (M - e) % M, (g, r, k1, k2)
     assert np.all(seen == 1)
+
+
+@pytest.mark.parametrize("np_,T,splits", [(1, 5, 1), (15, 40, 1), (16, 256, 1), (17, 300, 2), (150, 257, 1), (375, 70, 3), (160, 33, 4)])
+def test_toeplitz_block_time_axis(np_, T, splits):
+    """fdl_mfma.hpp: one bin's time axis as sums of 16 x 16 Toeplitz-block products -- tiles, partition splits, stage windows, the
+    LDS image index formulas and the operand positions of the kernel, restated in numpy -- equals the direct sum
+    Y[t] = sum_m H[m] X[t - m] over the FDL history (tau > -np) and the call's blocks."""
+    from kernel_model import mfma_chunks, mfma_time_axis
+    rng = np.random.default_rng(1000 * np_ + T)
+    H = rng.standard_normal(np_) + 1j * rng.standard_normal(np_)
+    xs = rng.standard_normal(np_ + T) + 1j * rng.standard_normal(np_ + T)          # X[tau] at index tau + np - 1 ... history first
+    X = lambda tau: xs[tau + np_ - 1]
+    got = mfma_time_axis(X, H, T, splits).sum(axis=0)
+    ref = np.array([sum(H[m] * X(t - m) for m in range(np_) if t - m > -np_) for t in range(T)])
+    assert np.abs(got - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    J = mfma_chunks(np_)
+    assert 16 * (J - 1) - 15 <= np_ - 1 < 16 * J            # the last chunk is needed, one more would multiply zeros only
