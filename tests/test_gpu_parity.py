@@ -702,13 +702,14 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
 
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 32, 19200, 1100), (3, 1, 64, 900, 50),
                                         (1, 2, 1024, 40000, 17), (1, 1, 2048, 9000, 5), (1, 2, 16, 700, 1300), (2, 1, 256, 96000, 40),
-                                        (1, 1, 64, 64 * 31, 70), (1, 1, 64, 64 * 33, 70)],
+                                        (1, 1, 64, 64 * 31, 70), (1, 1, 64, 64 * 33, 70), (1, 1, 64, 50, 40), (2, 1, 32, 33, 70), (1, 2, 16, 16 * 16, 300)],
                          ids=lambda v: str(v))
 def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
     """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_32x32x2_f32; the default for calls of
     >= 512 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
-    that end inside the first 1024-block tile or span two, partition counts around the 32-tap chunk edges, several partition
-    splits (P = 600: two LDS stages per split), packed bin 0, stereo IRs, history across calls (one signal as two calls)."""
+    that end inside the first 256-block tile or span several, partition counts around the 16-tap chunk edges (and 1, 2, 16 partitions:
+    a single Toeplitz chunk, whose upper triangle is all padding), several partition splits (P = 600), packed bin 0, stereo IRs,
+    history across calls (one signal as two calls)."""
     x = _streams(I, C, T * B, 955)
     irs = [np.stack([decaying_ir(960 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
