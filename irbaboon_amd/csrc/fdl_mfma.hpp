@@ -20,8 +20,9 @@
 // The range of j is walked in stages of kMfmaJC chunks: the H taps and X rows a stage needs go global -> registers -> LDS
 // (rows of 128 B: every line is used whole; buffer loads with the row step in an SGPR: no vector instruction per load) into one
 // half of the LDS while the other half is multiplied -- one barrier per stage of 9 chunks; 141 KiB of LDS for both --, X folded
-// as [k / 2][row][k % 2] so that the operand read of a 32-lane group (ds_read_b64) is one contiguous 256 bytes = every bank
-// once.  Per chunk a wave reads 8 operands of 8 bytes from LDS -- half a chunk ahead, in registers: a wave that waits for a
+// as [k][row]: the 16 lanes of an operand read that share a k read 16 consecutive rows = 128 contiguous bytes (hipcc pairs the
+// reads into ds_read2_b64, which is banked per 16 lanes and 32 banks: with k % 2 innermost SQ_LDS_BANK_CONFLICT was 29 % of the
+// LDS cycles, now 2 % -- the kernel's time did not move: LDS is not what it waits for).  Per chunk a wave reads 8 operands of 8 bytes from LDS -- half a chunk ahead, in registers: a wave that waits for a
 // ds_read lets the matrix pipe run dry -- and issues 16 v_mfma_f32_16x16x4_f32 (512 cycles of matrix pipe).  The 256 x 16 results leave through LDS as whole 128-byte
 // rows of part[s][t][split][M] (summed over splits by k_ifft_ola_run, like those of k_cmac_tiled_pk).
 //
@@ -52,7 +53,7 @@ constexpr int kMfmaXI = (kMfmaNC + 3) / 4, kMfmaHI = (kMfmaNH + 3) / 4;     // s
 // per-bin LDS strides in float2, 1 (mod 16): the 16 bins a 16-lane group of ds_write_b64 stages fall into the 32 banks once
 constexpr int kMfmaXS = kMfmaSeg * kMfmaNC + 1;
 constexpr int kMfmaHS = kMfmaSeg * kMfmaNH + 1;
-constexpr int kMfmaStage = kMfmaBins * (kMfmaXS + kMfmaHS);    // float2 per stage image: X as [bin][k / 2][X row][k % 2], then H as [bin][m]
+constexpr int kMfmaStage = kMfmaBins * (kMfmaXS + kMfmaHS);    // float2 per stage image: X as [bin][k][X row], then H as [bin][m]
 constexpr int kMfmaOS = kMfmaBins + 1;                 // row stride of the output tile in LDS
 constexpr size_t kMfmaLds = 2 * kMfmaStage * sizeof(float2);   // dynamic LDS of a launch (two stage images)
 static_assert(kMfmaSR == 4 * kMfmaSeg, "a staging pass is four X rows / four H chunks");
@@ -62,7 +63,7 @@ static_assert(kMfmaTile * kMfmaOS <= kMfmaStage, "the output tile reuses a stage
 __host__ __device__ constexpr int mfma_chunks(int np) { return np > 0 ? (np + kMfmaSeg - 2) / kMfmaSeg + 1 : 0; }
 
 // One stage of one wave: jc chunks of its bin out of a stage image.  Unit = half a chunk: X operand lane (n, kq) <- Xc[s0 + n - j][4 g + kq]
-// at xb[(2 g NC - j) 2], H operand lane (i, kq) <- H[16 j + i - 4 g - kq] at hb[16 j - 4 g], g = 0, 1 / 2, 3; the operands of the
+// at xb[4 g NC - j], H operand lane (i, kq) <- H[16 j + i - 4 g - kq] at hb[16 j - 4 g], g = 0, 1 / 2, 3; the operands of the
 // next unit are read while this one is multiplied.  PACKED (bin 0: DC and Nyquist, two real products) is a template parameter, the
 // last chunk is peeled: no branch between the MFMAs of a stage but the loop's own (with a wave-uniform `if (packed)` around every
 // unit the kernel executed 0.7 branches and 3.4 scalar instructions per MFMA, and one wave needed ~45 cycles per 32-cycle MFMA).
@@ -73,7 +74,7 @@ __device__ __forceinline__ void mfma_stage(const float2 *xb, const float2 *hb, i
 #pragma unroll
         for (int gg = 0; gg < 2; gg++) {
             const int g = 2 * half + gg;
-            x[gg] = xb[(2 * g * kMfmaNC - j) * 2];
+            x[gg] = xb[4 * g * kMfmaNC - j];
             h[gg] = hb[kMfmaSeg * j - 4 * g];
         }
     };
@@ -185,11 +186,11 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_cmac_mfma(StepArgs a)
         }
     };
     auto put = [&](int p) {
-        float2 *sx = l_stage + p * kMfmaStage + sbin * kMfmaXS + (((sk / 2) * kMfmaNC + sc) * 2 + sk % 2);
+        float2 *sx = l_stage + p * kMfmaStage + sbin * kMfmaXS + (sk * kMfmaNC + sc);
         float2 *sh = l_stage + p * kMfmaStage + kMfmaBins * kMfmaXS + sbin * kMfmaHS + srow;
 #pragma unroll
         for (int it = 0; it < kMfmaXI; it++)
-            if (4 * it + 3 < kMfmaNC || 4 * it + sc < kMfmaNC) sx[8 * it] = xr[it];
+            if (4 * it + 3 < kMfmaNC || 4 * it + sc < kMfmaNC) sx[4 * it] = xr[it];
 #pragma unroll
         for (int it = 0; it < kMfmaHI; it++)
             if (4 * it + 3 < kMfmaNH || 4 * it + sc < kMfmaNH) sh[kMfmaSR * it] = hr[it];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_cmac_mfma(StepArgs a)
     for (int v = 0; v < 4; v++) { acc_r[v] = 0.f; acc_n[v] = 0.f; acc_i[v] = 0.f; }
     const bool packed = b0 + wave == 0;                            // wave-uniform: the bin that holds DC and Nyquist
     auto multiply_stage = [&](int jc, int p) {
-        const float2 *xb = l_stage + p * kMfmaStage + wave * kMfmaXS + (((kq / 2) * kMfmaNC + n + jc - 1) * 2 + kq % 2);
+        const float2 *xb = l_stage + p * kMfmaStage + wave * kMfmaXS + (kq * kMfmaNC + n + jc - 1);
         const float2 *hb = l_stage + p * kMfmaStage + kMfmaBins * kMfmaXS + wave * kMfmaHS + (kMfmaSeg + n - kq);
         if (packed) mfma_stage<true>(xb, hb, jc, acc_r, acc_n, acc_i);
         else        mfma_stage<false>(xb, hb, jc, acc_r, acc_n, acc_i);

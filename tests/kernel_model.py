@@ -239,7 +239,7 @@ def mfma_time_axis(X, H, T, splits=1):
             for ja in range(jb, je, MFMA_JC):
                 jc = min(MFMA_JC, je - ja)
                 tau_lo, m_lo = MFMA_SEG * (s0 - ja - jc + 1), MFMA_SEG * ja - MFMA_SEG
-                # the stage images: X as [k / 2][X row][k % 2], H as [m - m_lo]; staging thread srow -> k = srow % 16, row 4 it + srow / 16
+                # the stage images: X as [k][X row], H as [m - m_lo]; staging thread srow -> k = srow % 16, row 4 it + srow / 16
                 lx = np.zeros(MFMA_SEG * MFMA_NC, np.complex128)
                 lh = np.zeros(MFMA_SEG * MFMA_NH, np.complex128)
                 for srow in range(64):
@@ -248,7 +248,7 @@ def mfma_time_axis(X, H, T, splits=1):
                         c = 4 * it + sc
                         if c < MFMA_NC:
                             ok = c < jc + MFMA_SEG - 1
-                            lx[((sk // 2) * MFMA_NC + sc) * 2 + sk % 2 + 8 * it] = x_at(tau_lo + srow + 64 * it) if ok else 0.0
+                            lx[sk * MFMA_NC + sc + 4 * it] = x_at(tau_lo + srow + 64 * it) if ok else 0.0
                     for it in range((MFMA_NH + 3) // 4):
                         if 4 * it + sc < MFMA_NH:
                             ok = 4 * it + sc < jc + 2
@@ -257,7 +257,7 @@ def mfma_time_axis(X, H, T, splits=1):
                 for j in range(jc):
                     for g in range(4):
                         for kq in range(4):
-                            xs = np.array([lx[((kq // 2) * MFMA_NC + n + jc - 1) * 2 + kq % 2 + (2 * g * MFMA_NC - j) * 2] for n in range(MFMA_SEG)])
+                            xs = np.array([lx[kq * MFMA_NC + n + jc - 1 + 4 * g * MFMA_NC - j] for n in range(MFMA_SEG)])
                             hs = np.array([lh[MFMA_SEG + i - kq + MFMA_SEG * j - 4 * g] for i in range(MFMA_SEG)])
                             acc += np.outer(xs, hs)                       # one k of v_mfma_f32_16x16x4: O[n][i] += X(n, k) * H(k, i)
             for n in range(MFMA_SEG):
