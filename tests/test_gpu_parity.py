@@ -731,6 +731,29 @@ def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
 
 
+def test_matrix_core_path_properties_at_the_full_baseline_size():
+    """configs[1] at its full size (B=256, 2-second IR, ONE call of 3750 blocks: the matrix-core kernel's bench shape), checked through
+    properties that need no oracle run: a two-tap IR (taps in partitions 0 and 195) gives the sum of two pure delays, and the call is
+    linear in its input (y(x1 + 2 x2) = y(x1) + 2 y(x2)) to rounding."""
+    B, Lh, T = 256, 96000, 3750
+    x1, x2 = white_noise(9901, T * B), white_noise(9902, T * B)
+    h = np.zeros(Lh, np.float32)
+    h[100], h[50000] = 1.0, -0.5
+    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=T) as eng:
+        eng.set_ir(0, h)
+        y = eng.process(x1[None, :])[0]
+        ref = np.zeros_like(x1)
+        ref[100:] += x1[:-100]
+        ref[50000:] -= 0.5 * x1[:-50000]
+        assert np.abs(y - ref).max() < 1e-5 * np.abs(ref).max() and rel_rms(y, ref) < 1e-6
+        eng.set_ir(0, decaying_ir(9903, Lh))
+        ys = []
+        for x in (x1, x2, x1 + 2.0 * x2):
+            eng.reset()
+            ys.append(eng.process(x[None, :])[0])
+    assert rel_rms(ys[2], ys[0] + 2.0 * ys[1]) < 1e-6
+
+
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513)], ids=lambda v: str(v))
 def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B, Lh, T):
     """No tuning variable set: a call of >= 512 blocks multiplies on the matrix cores (another summation order than the packed-FMA
