@@ -9,7 +9,7 @@ from irbaboon_amd.synth import decaying_ir, white_noise
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0, n, worst = time.time(), 0, 0.0
+t0, n, worst, t_said = time.time(), 0, 0.0, time.time()
 counts = {}
 while time.time() - t0 < budget:
     I = int(rng.choice([1, 1, 2, 3, 5, 9, 17, 40]))
@@ -63,4 +63,7 @@ while time.time() - t0 < budget:
             worst = max(worst, err)
             assert err < 1e-5, (I, C, B, cap, Lh, T, tmax, flags, env, i, c, err)
     n += 1
+    if time.time() - t_said > 60:                  # (a run that stays silent for minutes is taken to be hung)
+        t_said = time.time()
+        print(f"... {n} engines, worst so far {worst:.2e}", flush=True)
 print(f"{n} random engines in {time.time()-t0:.0f} s, worst rel RMS {worst:.2e}; by (flags, multi-workgroup): {counts}")
