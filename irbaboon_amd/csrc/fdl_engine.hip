@@ -307,30 +307,12 @@ int launch_cols(irb_fdl *h, irb::StepArgs a)
 int check_status(irb_fdl *h)
 {
     if (h->h_status && *h->h_status) {
+        // the host has waited for the stream (every caller does before it asks): nothing enqueued still reads the staging.
+        // No allocation, no stream, no pointer changes here -- this runs on the audio thread (include/irb_fdl.h: "after create
+        // no entry point allocates device memory")
         *h->h_status = 0;
         *h->h_done = 0;
-        if (h->host_io && env_int("IRB_RT_BAR", 1)) {
-            int large_bar = 0;
-            if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
-                const size_t nin = ((size_t) h->S * h->Tmax * h->B + 15) / 16 * 16, nir = ((size_t) h->P * h->B + 15) / 16 * 16;
-                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&h->bar_in), sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
-                    h->bar_ir = h->bar_in + nin;
-                    h->bar_mb = reinterpret_cast<irb::RtMailbox *>(h->bar_ir + nir);
-                    h->bytes += sizeof(float) * (nin + nir) + sizeof(irb::RtMailbox);
-                    std::memset(h->bar_mb, 0, sizeof(irb::RtMailbox));          // through the BAR, like everything the host puts there
-                    __builtin_ia32_sfence();
-                    if ((h->flags & IRB_FDL_RESIDENT) && hipStreamCreateWithFlags(&h->rt_stream, hipStreamNonBlocking) == hipSuccess) {
-                        h->resident = true;
-                        h->idle_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_IDLE_US", 20000)) * 100u;
-                        h->life_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_LIFE_MS", 10000)) * 100000u;
-                    }
-                } else {
-                    (void) hipGetLastError();                    // no such memory here: the pinned staging serves
-                    h->bar_in = nullptr;
-                }
-            }
-        }
-        h->part_slot_busy.assign((size_t) h->P, 0);
+        std::fill(h->part_slot_busy.begin(), h->part_slot_busy.end(), 0);
         return fail(IRB_ERR_STATE, "in-kernel hand-off timed out (a producer workgroup never published its slice)");
     }
     return IRB_OK;

@@ -32,6 +32,20 @@ int main(int argc, char **argv)
         if (y.getNumChannels() != 3 || y.getNumSamples() != 79) return 1;
         for (float v : y.d) if (v != 0.0f) return 2;
     }
+    {   // an adapter whose create failed (0 channels: no GPU needed to fail): the failure is reported ONCE, by the constructor;
+        // audio callbacks then clear their buffer and print nothing (this is the audio thread)
+        irb::RtConvolverT<PlanarBuffer> bad(0, 0, 256, 2048);
+        if (bad.ok()) return 7;
+        bad.prepareToPlay(256);
+        PlanarBuffer blk(2, 256);
+        for (int k = 0; k < 5; k++) {
+            for (auto &v : blk.d) v = 1.0f;
+            bad.processBlock(blk);
+            for (float v : blk.d) if (v != 0.0f) return 8;
+        }
+        bad.processBlockBypassed(blk);
+        if (bad.failedCallbacks() != 6) return 9;
+    }
     if (!gpu) { std::puts("layout ok"); return 0; }
     PlanarBuffer a(2, 4096), h(1, 2048);
     a.clear(); h.clear();

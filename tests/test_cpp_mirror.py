@@ -20,6 +20,8 @@ def test_cpp_mirror_layout_error_convention(hip_lib):
     r = subprocess.run([EXE, "layout"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "not mono nor stereo" in r.stderr
+    # the adapter whose create failed printed exactly one line, whatever the number of callbacks that followed
+    assert r.stderr.count("irb_rt:") == 1, r.stderr
 
 
 @pytest.mark.gpu

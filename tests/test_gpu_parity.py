@@ -3,6 +3,7 @@
 or float64 convolution.  Tolerance: the north star's 1e-5 relative RMS per channel (util.RMS_TOL);
 this is floating-point work, so bit-exactness is not expected (the MAC sums partitions in a
 different order than the reference's sequential loop, fp/convolution.cpp:171-202)."""
+import ctypes
 import os
 
 import numpy as np
@@ -705,7 +706,7 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
                                         (1, 1, 64, 64 * 31, 70), (1, 1, 64, 64 * 33, 70), (1, 1, 64, 50, 40), (2, 1, 32, 33, 70), (1, 2, 16, 16 * 16, 300)],
                          ids=lambda v: str(v))
 def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
-    """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_32x32x2_f32; the default for calls of
+    """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_16x16x4_f32; the default for calls of
     >= 512 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
     that end inside the first 256-block tile or span several, partition counts around the 16-tap chunk edges (and 1, 2, 16 partitions:
     a single Toeplitz chunk, whose upper triangle is all padding), several partition splits (P = 600), packed bin 0, stereo IRs,
@@ -1048,30 +1049,49 @@ def test_column_sliced_handoff_under_uneven_load():
     assert max(res) < 2e-6, res
 
 
-def test_granule_handoff_timeout_is_reported_and_recoverable(monkeypatch):
+@pytest.mark.parametrize("flags", [0, _lib.HOST_IO | _lib.STEPWISE], ids=["copy_mode", "host_io_stepwise"])
+def test_granule_handoff_timeout_is_reported_and_recoverable(monkeypatch, flags):
     """The tagged-granule hand-off of k_step_cols (the default for few streams, the plug-in's long-IR engines included) spins
     on other workgroups' stores with a 50 ms bound.  IRB_DEBUG_DROP_GRANULES=3 makes one producer of the third launch
     withhold its granules: that launch must END (no hang), the blocking call must report IRB_ERR_STATE exactly once, and
-    after irb_fdl_reset the handle must produce correct samples again."""
+    after irb_fdl_reset the handle must produce correct samples again.
+    flags = HOST_IO|STEPWISE is the shape the plug-in adapter creates for a long IR (Source/PluginProcessor.cpp:452-518 through
+    irb_fdl_process_refresh, "any other engine shape"): there the error path runs on the audio thread, so it must not allocate --
+    device_bytes is the same before and after -- and the handle's staging must still be the one the kernels read."""
     import time
     B, Lh, T = 256, 96000, 6
+    P = Lh // B
     x, h = white_noise(8100, T * B)[None], decaying_ir(8101, Lh)[None]
     monkeypatch.setenv("IRB_DEBUG_DROP_GRANULES", "3")
     monkeypatch.setenv("IRB_COLS_HANDOFF", "2")
-    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=1) as eng:
+    rt_shape = flags != 0
+    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=1, flags=flags) as eng:
         assert eng.info.splits > 1                                   # a multi-workgroup step: there is a hand-off to lose
         eng.set_ir(0, h)
-        eng.process(x[:, :B])
-        eng.process(x[:, B:2 * B])
+        bytes_before = eng.info.device_bytes
+
+        def step(k, part):
+            blk = x[:, k * B:(k + 1) * B]
+            return eng.process_refresh(blk, h[0], part % P) if rt_shape else eng.process(blk)
+
+        step(0, 0)
+        step(1, 1)
         t0 = time.perf_counter()
         with pytest.raises(_lib.IrbError) as e:
-            eng.process(x[:, 2 * B:3 * B])
+            step(2, 2)
         dt = time.perf_counter() - t0
         assert e.value.code == _lib.IRB_ERR_STATE and "hand-off timed out" in str(e.value)
         assert 0.03 < dt < 2.0                                       # the bounded spin (50 ms), not a hang
         eng.synchronize()                                            # reported once: the status word was consumed
+        info = _lib.FdlInfo()
+        _lib.check(_lib.lib().irb_fdl_get_info(eng._h, ctypes.byref(info)))
+        assert info.device_bytes == bytes_before                     # the error path allocated nothing
         eng.reset()
-        y = eng.process(x)
+        if rt_shape:
+            # every refresh rewrites a partition with the samples it already holds: plain convolution with h
+            y = np.concatenate([eng.process_refresh(x[:, k * B:(k + 1) * B], h[0], k % P) for k in range(T)], axis=1)
+        else:
+            y = eng.process(x)
     ref, _ = oracle.convolve_periodic(x, h, B)
     assert rel_rms(y[0], ref[0, :T * B]) < RMS_TOL
 
