@@ -53,8 +53,15 @@ extern "C" {
 #define IRB_FDL_NO_RT_KERNEL  0x80u /* irb_fdl_process_refresh: always the refresh launch + step launch per block (A/B, tests) */
 #define IRB_FDL_RESIDENT      0x100u /* irb_fdl_process_refresh (single stereo or mono instance, IRB_FDL_HOST_IO, large-BAR system): requests are served by
                                         a workgroup that stays resident on the GPU between callbacks (no kernel launch per callback); it exits
-                                        by itself after 20 ms without a request (the next callback starts a new one), after 10 s at the
-                                        latest, and whenever any other entry point of the handle is called                        */
+                                        by itself after 20 ms without a request (the next callback starts a new one), after 250 ms at the
+                                        latest, whenever any other entry point of the handle is called, and when any thread opens a quiet
+                                        section on the device (irb_device_quiet_begin).
+                                        WHAT A LIVE SERVER MEANS FOR THE REST OF THE PROCESS: hipFree, hipHostFree, hipDeviceSynchronize and
+                                        anything else that waits for every stream of the device wait for the server kernel too.  Every such
+                                        call inside this library is bracketed by a quiet section, so prepareToPlay / releaseResources of
+                                        another instance or a one-shot irb_convolve_periodic are never held up by it (tests:
+                                        test_resident_server_does_not_stall_other_handles).  The host's OWN device-wide waits should be
+                                        bracketed with irb_device_quiet_begin / _end; one that is not waits at most the 250 ms lifetime cap. */
 
 typedef struct irb_fdl irb_fdl;          /* batched FDL convolver, device resident  */
 typedef struct irb_rt irb_rt;            /* processBlock-shaped adapter on top      */
@@ -199,6 +206,41 @@ int  irb_convolve_periodic(int device,
                            const float *const *ir, int ir_ch, int Lh,
                            int processBlockSize, int keep_reference_tail,
                            float *const *out);
+
+/* Quiet section (no reference counterpart: the reference runs on the CPU and owns no device): between _begin and _end no
+ * resident real-time server (IRB_FDL_RESIDENT) runs on `device` -- live ones leave after the request in hand, audio threads
+ * serve their callbacks with one kernel launch each and resume the resident form afterwards -- so that a device-wide
+ * runtime wait made in between (hipFree, hipHostFree, hipDeviceSynchronize, by the host or by another library) is not held
+ * up by a server kernel.  Counted: sections may nest and overlap across threads.  Every such wait inside this library
+ * already sits in one. */
+int  irb_device_quiet_begin(int device);
+int  irb_device_quiet_end(int device);
+
+/* Where the time of the calling thread's last irb_convolve_periodic call went (measurement support for bench.py; no reference
+ * counterpart: fp::convolution::convolvePeriodic, fp/convolution.cpp:14-242, has no timing code).  Host figures are wall-clock
+ * milliseconds on the thread that did the work; they overlap each other and the device figures (the call is a pipeline), so
+ * they do not add up to total_ms.  Device figures are sums over the chunks of hipEvent intervals on the queues the work ran
+ * on, collected only while irb_convolve_profile_events(1) is in force (-1 otherwise: reading events costs host time). */
+typedef struct irb_convolve_profile {
+    double total_ms;            /* the whole call                                                           */
+    double setup_ms;            /* engine look-up (or creation: engine_created), FDL reset, IR upload + transform enqueued */
+    double pack_ms;             /* calling thread: caller's audio -> pinned staging                         */
+    double unpack_ms;           /* unpacking thread (or the calling thread): pinned staging -> caller's out */
+    double wait_ms;             /* the unpacking side blocked on the chunks' completion events              */
+    double stall_ms;            /* the calling thread blocked on the unpacking side (slot reuse, end of call) */
+    double h2d_ms, kernels_ms, d2h_ms;   /* device: copy queue in, the three kernels per chunk, copy queue out */
+    int chunks, blocks_per_chunk, last_chunk_blocks, steps;     /* steps = floor(La/B) + P (+1 without the reference's dropped tail) */
+    int slots, zero_copy, helper_thread, engine_created, mac_on_matrix_cores;
+} irb_convolve_profile;
+int  irb_convolve_last_profile(irb_convolve_profile *out);
+/* switch the device-event part of the profile on / off for the whole process; returns the previous setting (measurement
+ * support; no reference counterpart) */
+int  irb_convolve_profile_events(int on);
+
+/* Which kernel a call of n_blocks blocks per stream multiplies with on this handle ("k_step_fused", "k_step_cols",
+ * "k_cmac_tiled_pk<16,8>", "k_cmac_mfma" ...): what the handle's geometry, the device and the tuning overrides selected at
+ * create, not a guess.  Measurement support; no reference counterpart (the reference has one loop, fp/convolution.cpp:171-202). */
+const char *irb_fdl_mac_kernel_name(const irb_fdl *h, int n_blocks);
 
 /* ---- several GPUs from one host process ------------------------------------------------------------------
  * No reference counterpart (the reference is one plug-in instance on one CPU thread); the per-instance work is

@@ -35,6 +35,15 @@ class FdlInfo(C.Structure):
                 ("algorithmic_bytes_per_block_step", C.c_double)]
 
 
+class ConvolveProfile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("total_ms", "setup_ms", "pack_ms", "unpack_ms", "wait_ms", "stall_ms", "h2d_ms", "kernels_ms", "d2h_ms")] + \
+               [(n, C.c_int) for n in ("chunks", "blocks_per_chunk", "last_chunk_blocks", "steps", "slots", "zero_copy", "helper_thread",
+                                       "engine_created", "mac_on_matrix_cores")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # every symbol include/irb_fdl.h and include/irb_deconv.h declare: (name, restype, argtypes)
 SYMBOLS = [
     ("irb_fdl_create", C.c_int, [C.POINTER(FdlConfig), C.POINTER(C.c_void_p)]),
@@ -65,6 +74,11 @@ SYMBOLS = [
     ("irb_fdl_multi_reset", C.c_int, [C.c_void_p]),
     ("irb_fdl_multi_process", C.c_int, [C.c_void_p, fpp, fpp, C.c_int]),
     ("irb_convolve_periodic", C.c_int, [C.c_int, fpp, C.c_int, C.c_int, fpp, C.c_int, C.c_int, C.c_int, C.c_int, fpp]),
+    ("irb_device_quiet_begin", C.c_int, [C.c_int]),
+    ("irb_device_quiet_end", C.c_int, [C.c_int]),
+    ("irb_convolve_last_profile", C.c_int, [C.POINTER(ConvolveProfile)]),
+    ("irb_convolve_profile_events", C.c_int, [C.c_int]),
+    ("irb_fdl_mac_kernel_name", C.c_char_p, [C.c_void_p, C.c_int]),
     ("irb_rt_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_rt_destroy", None, [C.c_void_p]),
     ("irb_rt_prepare_to_play", C.c_int, [C.c_void_p, C.c_int]),

@@ -246,6 +246,7 @@ void irb_lfft_destroy(irb_lfft *p)
     if (!p) return;
     (void) hipSetDevice(p->device);
     if (p->stream) (void) hipStreamSynchronize(p->stream);
+    (void) irb_device_quiet_begin(p->device);          // the frees wait for every stream of the device: resident real-time servers step aside
     (void) hipFree(p->d_tw1); (void) hipFree(p->d_tw2); (void) hipFree(p->d_tabA); (void) hipFree(p->d_tabB);
     (void) hipFree(p->d_w0); (void) hipFree(p->d_w1); (void) hipFree(p->d_time); (void) hipFree(p->d_spec);
     if (p->h_log) (void) hipHostFree(p->h_log);
@@ -253,6 +254,7 @@ void irb_lfft_destroy(irb_lfft *p)
     free_windows(p->win);
     for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
     if (p->stream) (void) hipStreamDestroy(p->stream);
+    (void) irb_device_quiet_end(p->device);
     delete p;
 }
 

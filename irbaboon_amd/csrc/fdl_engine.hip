@@ -7,13 +7,18 @@
 #include "fdl_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -405,6 +410,51 @@ void update_pairing(irb_fdl *h)
     for (int i = 0; i < h->I && h->pair; i++) h->pair = h->h_set_of_stream[2 * i] == h->h_set_of_stream[2 * i + 1];
 }
 
+// ---- resident real-time servers and the rest of the process -----------------------------------------------------------
+// A live k_rt_server occupies its stream for as long as callbacks keep arriving.  hipFree, hipHostFree and
+// hipDeviceSynchronize wait for EVERY stream of the device, so another plug-in instance's prepareToPlay / releaseResources,
+// a one-shot irb_convolve_periodic that swaps its cached engine, or a thread-exit guard would wait for that server's
+// lifetime.  A "quiet section" (DeviceQuiet, irb_device_quiet_begin / _end) brackets every such call in this library: it
+// raises a per-device count and posts the yield word of every resident-capable handle on the device.  A server leaves
+// after the request in hand; while the count is raised an audio thread serves its callbacks with one k_rt_pair launch each
+// (an ordinary kernel of a few microseconds) instead of starting a server, and resumes the resident form afterwards.
+constexpr int kMaxDevices = 64;
+std::mutex g_reg_mu;
+std::vector<irb_fdl *> g_resident;                    // handles that own a mailbox (created with IRB_FDL_RESIDENT on a large-BAR device)
+std::atomic<int> g_quiet[kMaxDevices];                // threads inside a quiet section, per device
+
+bool device_quiet(int dev) { return dev >= 0 && dev < kMaxDevices && g_quiet[dev].load(std::memory_order_seq_cst) > 0; }
+
+void quiet_begin(int dev)
+{
+    if (dev < 0 || dev >= kMaxDevices) return;
+    g_quiet[dev].fetch_add(1, std::memory_order_seq_cst);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (irb_fdl *o : g_resident)
+        if (o->device == dev && o->bar_mb) o->bar_mb->yield = 1;       // through the BAR; the owner clears it when it next starts a server
+    __builtin_ia32_sfence();
+}
+
+void quiet_end(int dev)
+{
+    if (dev >= 0 && dev < kMaxDevices) g_quiet[dev].fetch_sub(1, std::memory_order_seq_cst);
+}
+
+struct DeviceQuiet {
+    int dev;
+    explicit DeviceQuiet(int d) : dev(d) { quiet_begin(dev); }
+    ~DeviceQuiet() { quiet_end(dev); }
+    DeviceQuiet(const DeviceQuiet &) = delete;
+    DeviceQuiet &operator=(const DeviceQuiet &) = delete;
+};
+
+void registry_add(irb_fdl *h) { std::lock_guard<std::mutex> lk(g_reg_mu); g_resident.push_back(h); }
+void registry_remove(irb_fdl *h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_resident.erase(std::remove(g_resident.begin(), g_resident.end(), h), g_resident.end());
+}
+
 // ---- resident real-time server (k_rt_server) --------------------------------------------------------------------------
 // the generation word the server stores last lives next to the completion word (h_done[1])
 inline volatile unsigned *exited_word(irb_fdl *h) { return h->h_done + 1; }
@@ -416,6 +466,8 @@ int server_launch(irb_fdl *h, unsigned first_seq)
     irb::StepArgs a = step_args(h, h->bar_in, h->d_hio + (size_t) h->S * h->Tmax * h->B, (long) h->Tmax * h->B);
     a.rf_src = h->bar_ir; a.done = h->d_done;
     if (++h->server_gen == 0) ++h->server_gen;           // 0 is the exited word's initial value
+    h->bar_mb->yield = 0;                                // whatever an earlier quiet section posted
+    __builtin_ia32_sfence();
     h->n_launches++;
     if (h->C == 2) {
         FOR_N_RT(h->N, irb::k_rt_server<NN, 2><<<dim3(h->I), dim3(irb::kThreads), 0, h->rt_stream>>>(
@@ -426,6 +478,9 @@ int server_launch(irb_fdl *h, unsigned first_seq)
     }
     HIP_TRY(hipGetLastError());
     h->server_live = true;
+    // a quiet section that began between the caller's check and the store above had its yield word overwritten: post it again
+    // (a section that begins after this line posts it itself)
+    if (device_quiet(h->device)) { h->bar_mb->yield = 1; __builtin_ia32_sfence(); }
     return IRB_OK;
 }
 
@@ -457,24 +512,111 @@ int upload_maps(irb_fdl *h)
 
 }  // namespace
 
-// irb_convolve_periodic's cached engine, one per calling thread.  The guard frees it (HBM, pinned staging, stream) when the
-// thread exits -- a plug-in host's pool thread that made one-shot calls must not leak an engine; irb_release_cached_plans()
-// is the explicit form.  (For the main thread this runs at exit(), before the HIP runtime's own static teardown.)
+// irb_convolve_periodic's cached engine and chunk pipeline, one per calling thread.  The guard frees everything (HBM, pinned
+// staging, streams, the unpacking thread) when the thread exits -- a plug-in host's pool thread that made one-shot calls
+// must not leak an engine; irb_release_cached_plans() is the explicit form.  (For the main thread this runs at exit(),
+// before the HIP runtime's own static teardown.)
 extern "C" void irb_fdl_destroy(irb_fdl *h);
 namespace {
+
+double now_ms()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+// The second host thread of a one-shot call: while the calling thread packs chunk c + 1 into pinned memory and enqueues it,
+// this one waits for chunk c - 1 and copies its samples out to the caller's buffer (the two host copies are most of a
+// call's time; on one thread they add up).  It sleeps on a condition variable between calls and makes no HIP call but
+// hipEventSynchronize / hipEventElapsedTime.
+struct Unpacker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int(int)> job;                       // chunk -> IRB_* code; valid while `active`
+    std::atomic<int> enqueued{0}, unpacked{0}, limit{0}, rc{0};
+    bool active = false, quit = false;
+    void run()
+    {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return active || quit; });
+                if (quit) return;
+            }
+            for (int c = 0; c < limit.load(std::memory_order_acquire); c++) {
+                while (enqueued.load(std::memory_order_acquire) <= c && c < limit.load(std::memory_order_acquire)) __builtin_ia32_pause();
+                if (c >= limit.load(std::memory_order_acquire)) break;
+                const int r = job(c);
+                if (r != IRB_OK) rc.store(r);
+                unpacked.store(c + 1, std::memory_order_release);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                active = false;
+            }
+            cv.notify_all();
+        }
+    }
+    void begin(int nc, std::function<int(int)> f)
+    {
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        job = std::move(f);
+        enqueued.store(0); unpacked.store(0); rc.store(0); limit.store(nc);
+        { std::lock_guard<std::mutex> lk(mu); active = true; }
+        cv.notify_all();
+    }
+    int finish()                                       // after the last post (or after lowering `limit`): wait for the worker to go idle
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !active; });
+        job = nullptr;
+        return rc.load();
+    }
+    void stop()
+    {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        th.join();
+        quit = false;
+    }
+};
+
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;
-    float *stage = nullptr;                            // pinned: two slots of [input | output][C][Tmax*B] for the chunk pipeline
-    hipEvent_t ev[2] = {nullptr, nullptr};             // recorded behind each slot's D2H copy
+    int D = 0;                                         // staging slots (chunks in flight)
+    size_t half = 0;                                   // floats per slot half (input or output): C * Tmax * B
+    float *stage = nullptr, *d_stage = nullptr;        // pinned [D][input | output][C][Tmax*B] and its device address (mapped)
+    float *d_io = nullptr;                             // device  [D][input | output][C][Tmax*B] (copy mode)
+    hipStream_t s_in = nullptr, s_out = nullptr;       // H2D and D2H queues beside the engine's own stream
+    // per slot: [0] before H2D, [1] H2D done, [2] kernels done, [3] D2H done (timing enabled: the profile reads them)
+    std::vector<hipEvent_t> ev;
+    Unpacker unpacker;
+    irb_convolve_profile prof;
+    bool have_prof = false;
     void release()
     {
+        unpacker.stop();
+        if (!eng) return;                              // (everything else is created together with the engine)
+        DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
+        (void) hipSetDevice(eng->device);
+        (void) irb_sync(eng);
+        if (s_in) { (void) hipStreamSynchronize(s_in); (void) hipStreamDestroy(s_in); s_in = nullptr; }
+        if (s_out) { (void) hipStreamSynchronize(s_out); (void) hipStreamDestroy(s_out); s_out = nullptr; }
         if (eng) { irb_fdl_destroy(eng); eng = nullptr; }
-        if (stage) { (void) hipHostFree(stage); stage = nullptr; }
-        for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
+        if (stage) { (void) hipHostFree(stage); stage = nullptr; d_stage = nullptr; }
+        if (d_io) { (void) hipFree(d_io); d_io = nullptr; }
+        for (auto &e : ev) if (e) (void) hipEventDestroy(e);
+        ev.clear();
+        D = 0; half = 0;
     }
     ~OfflineEngineGuard() { release(); }
 };
 thread_local OfflineEngineGuard g_offline;
+std::atomic<bool> g_offline_profile_events{false};     // irb_convolve_profile_events(): read the chunks' device events into the profile
+constexpr int kOfflineChunk = 1024;                       // blocks per chunk of irb_convolve_periodic (IRB_OFFLINE_CHUNK); see profiles/r04_oneshot_sweep.txt
 }
 
 extern "C" {
@@ -488,7 +630,9 @@ void irb_fdl_destroy(irb_fdl *h)
     if (!h) return;
     (void) hipSetDevice(h->device);
     (void) server_stop(h);
+    registry_remove(h);                                  // (no other thread posts into this handle's mailbox from here on)
     if (h->stream) (void) irb_sync(h);
+    DeviceQuiet quiet(h->device);                        // the frees below wait for every stream of the device: other instances' servers step aside
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
@@ -625,7 +769,10 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
                     if ((h->flags & IRB_FDL_RESIDENT) && hipStreamCreateWithFlags(&h->rt_stream, hipStreamNonBlocking) == hipSuccess) {
                         h->resident = true;
                         h->idle_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_IDLE_US", 20000)) * 100u;
-                        h->life_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_LIFE_MS", 10000)) * 100000u;
+                        // lifetime cap: the longest a device-wide wait made OUTSIDE this library (a host's own hipFree or
+                        // hipDeviceSynchronize) can be held up by continuous callbacks; a generation change costs one launch
+                        h->life_ticks = (unsigned) std::max(1, env_int("IRB_RT_SERVER_LIFE_MS", 250)) * 100000u;
+                        registry_add(h);
                     }
                 } else {
                     (void) hipGetLastError();                    // no such memory here: the pinned staging serves
@@ -668,6 +815,21 @@ int irb_fdl_get_info(const irb_fdl *h, irb_fdl_info *info)
     info->device_bytes = h->bytes;
     info->algorithmic_bytes_per_block_step = 8.0 * h->P * h->N + 16.0 * h->B;
     return IRB_OK;
+}
+
+const char *irb_fdl_mac_kernel_name(const irb_fdl *h, int n_blocks)
+{
+    if (!h || n_blocks < 1) return "";
+    const int T = h->stepwise ? 1 : std::min(n_blocks, h->Tmax);
+    if (T == 1) {
+        if (h->colW > 0) return "k_step_cols";
+        if (h->splits > 1) return (h->flags & IRB_FDL_SPLIT_3LAUNCH) ? "k_cmac_partial" : "k_step_split";
+        return (h->pair && h->N <= 2048) ? "k_step_fused_pair" : "k_step_fused";
+    }
+    if (use_mfma(h, T)) return "k_cmac_mfma";
+    if (h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048) return "k_cmac_tiled1<16>";
+    if (h->tiled_kernel == 0) return "k_cmac_tiled<8>";
+    return tile_outputs(h, T) == 8 ? "k_cmac_tiled_pk<8,4>" : "k_cmac_tiled_pk<16,8>";
 }
 
 int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_channels, int len)
@@ -942,7 +1104,9 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
     const bool one_launch = h->host_io && h->I == 1 && (h->pair || h->C == 1) && h->colW == 0 && h->splits <= 1 && h->N <= 1024 &&
                             !(h->flags & IRB_FDL_NO_RT_KERNEL);
     if (h->ir_used[0]) { h->n_waits++; HIP_TRY(hipEventSynchronize(h->ev_ir[0])); h->ir_used[0] = false; }   // slot 0 of the IR staging is about to be rewritten
-    if (one_launch && h->resident) {
+    // (not while a quiet section is open on this device -- another thread of the process is inside a device-wide runtime wait
+    // that a live server would hold up: the callback then takes the one-launch form below)
+    if (one_launch && h->resident && !(device_quiet(h->device) && (!h->server_live || *exited_word(h) == h->server_gen))) {
         // the resident server: post the request into the BAR mailbox (samples and parameters, a store fence, the request
         // number), make sure a server generation is alive, spin on the completion word
         for (int s = 0; s < h->S; s++) std::memcpy(h->bar_in + (size_t) s * stride, in[s], sizeof(float) * n);
@@ -957,6 +1121,7 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
         h->bar_mb->seq = seq;
         __builtin_ia32_sfence();
         volatile unsigned *done = h->h_done, *exited = exited_word(h);
+        bool served = true;
         if (!h->server_live || *exited == h->server_gen) { int rc = server_launch(h, seq); if (rc != IRB_OK) return rc; }
         h->n_waits++;
         timespec t0;
@@ -964,8 +1129,9 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
         for (unsigned spins = 0; *done != seq; spins++) {
             __builtin_ia32_pause();
             if ((spins & 255u) != 255u) continue;
-            if (*exited == h->server_gen && *done != seq) {          // that generation left (idle / lifetime) without this request: the next one takes it
-                int rc = server_launch(h, seq);
+            if (*exited == h->server_gen && *done != seq) {          // that generation left (idle / lifetime / yield) without this request
+                if (device_quiet(h->device)) { served = false; break; }     // ... because the device is wanted quiet: one launch serves this callback
+                int rc = server_launch(h, seq);                      // ... otherwise the next generation takes it
                 if (rc != IRB_OK) return rc;
                 continue;
             }
@@ -976,10 +1142,13 @@ int irb_fdl_process_refresh(irb_fdl *h, int instance, const float *const *in, fl
                 return fail(IRB_ERR_STATE, "real-time server did not answer within 200 ms");
             }
         }
-        h->t += n_blocks;
-        const float *res = h->h_io + (size_t) h->S * stride;
-        for (int s = 0; s < h->S; s++) std::memcpy(out[s], res + (size_t) s * stride, sizeof(float) * n);
-        return IRB_OK;
+        if (served) {
+            h->t += n_blocks;
+            const float *res = h->h_io + (size_t) h->S * stride;
+            for (int s = 0; s < h->S; s++) std::memcpy(out[s], res + (size_t) s * stride, sizeof(float) * n);
+            return IRB_OK;
+        }
+        // the posted request number stays behind unanswered: later generations start from their own first request and never match it
     }
     STOP_SERVER(h);
     if (one_launch) {
@@ -1068,7 +1237,14 @@ void *irb_host_alloc(size_t bytes)
     return p;
 }
 
-void irb_host_free(void *p) { if (p) (void) hipHostFree(p); }
+void irb_host_free(void *p)
+{
+    if (!p) return;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    DeviceQuiet quiet(dev);
+    (void) hipHostFree(p);
+}
 
 int irb_fdl_mark(irb_fdl *h, int slot)
 {
@@ -1143,73 +1319,196 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;    // samples this call produces (:225-227)
     clear_out(lim);                                                                 // the dropped tail stays 0 (:236-238)
 
-    // The signal goes through in chunks of at most 1024 blocks, two pinned staging slots deep: while the GPU copies and
-    // convolves chunk c, this thread unpacks chunk c-2 and packs chunk c+1 (the host copies in and out of pinned memory
-    // are two thirds of a call's time; round 2 did them strictly before and after the GPU work).
-    const int nc = (int) ((steps + 1023) / 1024), Tc = (int) ((steps + nc - 1) / nc);
+    // ---- the chunk pipeline ---------------------------------------------------------------------------------------------
+    // The signal goes through in chunks of whole 256-block tiles of the matrix-core MAC (all but the last chunk; the last one
+    // takes the remainder, so no chunk is shorter than IRB_OFFLINE_CHUNK blocks unless the whole call is), D staging slots deep:
+    //   calling thread : pack chunk c into pinned memory, enqueue H2D (own queue) -> kernels (engine's stream) -> D2H (own queue)
+    //   unpacking thread: wait for chunk c's D2H, copy its samples to the caller's buffer
+    // so the two host copies (most of a call's time), the three PCIe/compute queues and nothing else overlap.
+    const double t_begin = now_ms();
+    irb_convolve_profile prof;
+    std::memset(&prof, 0, sizeof prof);
+    const int chunk_pref = std::max(1, (env_int("IRB_OFFLINE_CHUNK", kOfflineChunk) + 255) / 256 * 256);
+    const int nc = (int) std::max<long>(1, steps / chunk_pref);
+    auto chunk_first = [&](int c) { return (long) c * chunk_pref; };
+    auto chunk_blocks = [&](int c) { return (int) (c == nc - 1 ? steps - chunk_first(c) : chunk_pref); };
+    const int Tneed = chunk_blocks(nc - 1);                                          // the longest chunk (< 2 * chunk_pref)
+    const int mode = env_int("IRB_OFFLINE_MODE", 0);                                 // 0 staged copies, 1 zero copy (kernels read / write the pinned staging)
+    const bool use_helper = env_int("IRB_OFFLINE_HELPER", 1) != 0 && nc > 1;
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     irb_fdl *h = g_offline.eng;
-    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= Tc && h->Tmax <= 8 * Tc + 64)) {
+    const int Dwant = std::min(nc, std::max(2, env_int("IRB_OFFLINE_SLOTS", 4)));
+    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= Tneed && h->Tmax <= 8 * Tneed + 64 &&
+          g_offline.D >= Dwant)) {
         g_offline.release();
         irb_fdl_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = P * B;
-        cfg.max_blocks_per_call = Tc;
+        cfg.max_blocks_per_call = nc > 1 ? 2 * chunk_pref - 1 : Tneed;              // any later call of this block size and IR length fits
         int rc0 = irb_fdl_create(&cfg, &h);
         if (rc0 != IRB_OK) return rc0;
         g_offline.eng = h;
-        const size_t slot = (size_t) 2 * audio_ch * h->Tmax * B;                     // per slot: input and output, [C][Tmax*B] each
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&g_offline.stage), sizeof(float) * 2 * slot);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev[0], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev[1], hipEventDisableTiming);
+        g_offline.D = nc > 1 ? std::max(Dwant, 4) : 1;
+        g_offline.half = (size_t) audio_ch * h->Tmax * B;
+        const size_t total = (size_t) g_offline.D * 2 * g_offline.half;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&g_offline.stage), sizeof(float) * total, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&g_offline.d_stage), g_offline.stage, 0);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g_offline.d_io), sizeof(float) * total);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_out, hipStreamNonBlocking);
+        g_offline.ev.assign((size_t) g_offline.D * 4, nullptr);
+        for (auto &ev : g_offline.ev) if (e == hipSuccess) e = hipEventCreate(&ev);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline staging: %s", hipGetErrorString(e)); }
+        prof.engine_created = 1;
     }
+    OfflineEngineGuard &g = g_offline;
+    const int D = g.D;
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
     rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
     if (rc != IRB_OK) return rc;
     const long stride = (long) h->Tmax * h->B;
-    const size_t half = (size_t) audio_ch * stride;                                  // floats per staging half (input or output)
-    auto s_in = [&](int c) { return g_offline.stage + (size_t) (c & 1) * 2 * half; };
-    auto s_out = [&](int c) { return s_in(c) + half; };
-    auto chunk_blocks = [&](int c) { return (int) std::min<long>(Tc, steps - (long) c * Tc); };
+    auto ev_of = [&](int c, int k) { return g.ev[(size_t) (c % D) * 4 + k]; };
+    auto host_in = [&](int c) { return g.stage + (size_t) (c % D) * 2 * g.half; };
+    auto host_out = [&](int c) { return host_in(c) + g.half; };
+    auto dev_in = [&](int c) { return (mode == 1 ? g.d_stage : g.d_io) + (size_t) (c % D) * 2 * g.half; };
+    auto dev_out = [&](int c) { return dev_in(c) + g.half; };
+    prof.setup_ms = now_ms() - t_begin;
+    const bool device_times = g_offline_profile_events;
+    double pack_ms = 0, unpack_ms = 0, wait_ms = 0, h2d_ms = 0, kern_ms = 0, d2h_ms = 0;     // unpack_*, wait_*, device times: written by the unpacking side only
+
     auto unpack = [&](int c) -> int {                                               // wait for chunk c, copy its samples out
-        h->n_waits++;
-        hipError_t e = hipEventSynchronize(g_offline.ev[c & 1]);
+        const double t0 = now_ms();
+        hipError_t e = hipEventSynchronize(ev_of(c, 3));
         if (e != hipSuccess) return fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-        const long s0 = (long) c * Tc * B, n = (long) chunk_blocks(c) * B;
+        const double t1 = now_ms();
+        const long s0 = chunk_first(c) * B, n = (long) chunk_blocks(c) * B;
         const long take = std::max<long>(0, std::min<long>(n, lim - s0));
         for (int ch = 0; ch < audio_ch; ch++)
-            if (take > 0) std::memcpy(out[ch] + s0, s_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) take);
+            if (take > 0) std::memcpy(out[ch] + s0, host_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) take);
+        if (device_times) {
+            float ms = 0;
+            if (mode == 0 && hipEventElapsedTime(&ms, ev_of(c, 0), ev_of(c, 1)) == hipSuccess) h2d_ms += ms;
+            if (hipEventElapsedTime(&ms, ev_of(c, 1), ev_of(c, 2)) == hipSuccess) kern_ms += ms;
+            if (mode == 0 && hipEventElapsedTime(&ms, ev_of(c, 2), ev_of(c, 3)) == hipSuccess) d2h_ms += ms;
+        }
+        wait_ms += t1 - t0;
+        unpack_ms += now_ms() - t1;
         return IRB_OK;
     };
-    for (int c = 0; c < nc && rc == IRB_OK; c++) {
-        if (c >= 2) { rc = unpack(c - 2); if (rc != IRB_OK) break; }                 // frees the staging slot this chunk reuses
-        const int nb = chunk_blocks(c);
-        const long s0 = (long) c * Tc * B, n = (long) nb * B;
-        for (int ch = 0; ch < audio_ch; ch++) {
-            float *dst = s_in(c) + (size_t) ch * stride;
-            const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));
-            if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
-            std::fill(dst + have, dst + n, 0.0f);
-        }
-        hipError_t e = hipSuccess;
-        for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)       // only the blocks of this chunk, per channel
-            e = COPY_ASYNC(h, h->d_in + (size_t) ch * stride, s_in(c) + (size_t) ch * stride, sizeof(float) * (size_t) n,
-                           hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-        rc = irb_fdl_process_device(h, h->d_in, h->d_out, stride, nb);
-        if (rc != IRB_OK) break;
-        for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)
-            e = COPY_ASYNC(h, s_out(c) + (size_t) ch * stride, h->d_out + (size_t) ch * stride, sizeof(float) * (size_t) n,
-                           hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipEventRecord(g_offline.ev[c & 1], h->stream);
-        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
+    if (use_helper) {
+        const int dev = device;
+        g.unpacker.begin(nc, [&, dev](int c) { (void) hipSetDevice(dev); return unpack(c); });
     }
-    for (int c = std::max(0, nc - 2); c < nc && rc == IRB_OK; c++) rc = unpack(c);
-    if (rc != IRB_OK) (void) irb_sync(h);             // nothing of a failed call may still be writing the staging
+    auto slot_is_free = [&](int c) -> int {                                          // chunk c - D has left the slot chunk c reuses
+        if (c < D) return IRB_OK;
+        if (!use_helper) return unpack(c - D);
+        const double t0 = now_ms();
+        while (g.unpacker.unpacked.load(std::memory_order_acquire) < c - D + 1) __builtin_ia32_pause();
+        prof.stall_ms += now_ms() - t0;
+        return g.unpacker.rc.load();
+    };
+    int enq = 0;
+    for (int c = 0; c < nc && rc == IRB_OK; c++) {
+        rc = slot_is_free(c);
+        if (rc != IRB_OK) break;
+        const int nb = chunk_blocks(c);
+        const long s0 = chunk_first(c) * B, n = (long) nb * B;
+        const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));      // samples of this chunk that hold audio
+        const long have_b = (have + B - 1) / B * B;                                  // ... rounded to whole blocks: what is copied; the flush blocks are zeroed on the device
+        const double t0 = now_ms();
+        for (int ch = 0; ch < audio_ch; ch++) {
+            float *dst = host_in(c) + (size_t) ch * stride;
+            if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
+            std::fill(dst + have, dst + (mode == 1 ? n : have_b), 0.0f);
+        }
+        pack_ms += now_ms() - t0;
+        hipError_t e = hipSuccess;
+        if (mode == 0) {
+            // the device slot is rewritten: the kernels of chunk c - D have read it (their event), and its output half has been copied out (D2H event)
+            if (c >= D) e = hipStreamWaitEvent(g.s_in, ev_of(c, 2), 0);
+            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 0), g.s_in);
+            for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++) {
+                if (have_b > 0) e = COPY_ASYNC(h, dev_in(c) + (size_t) ch * stride, host_in(c) + (size_t) ch * stride, sizeof(float) * (size_t) have_b,
+                                               hipMemcpyHostToDevice, g.s_in);
+                if (e == hipSuccess && n > have_b) e = hipMemsetAsync(dev_in(c) + (size_t) ch * stride + have_b, 0, sizeof(float) * (size_t) (n - have_b), g.s_in);
+            }
+            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 1), g.s_in);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev_of(c, 1), 0);
+        } else {
+            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 1), h->stream);
+        }
+        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
+        rc = irb_fdl_process_device(h, dev_in(c), dev_out(c), stride, nb);
+        if (rc != IRB_OK) break;
+        e = hipEventRecord(ev_of(c, 2), h->stream);
+        if (mode == 0) {
+            if (e == hipSuccess) e = hipStreamWaitEvent(g.s_out, ev_of(c, 2), 0);
+            for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)
+                e = COPY_ASYNC(h, host_out(c) + (size_t) ch * stride, dev_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) n,
+                               hipMemcpyDeviceToHost, g.s_out);
+            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 3), g.s_out);
+        } else if (e == hipSuccess) {
+            e = hipEventRecord(ev_of(c, 3), h->stream);
+        }
+        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
+        enq = c + 1;
+        if (use_helper) g.unpacker.enqueued.store(enq, std::memory_order_release);
+    }
+    if (use_helper) {
+        g.unpacker.limit.store(enq, std::memory_order_release);                      // (a failed call: what was enqueued is still drained)
+        const double t0 = now_ms();
+        const int rcu = g.unpacker.finish();
+        prof.stall_ms += now_ms() - t0;
+        if (rc == IRB_OK && rcu != IRB_OK) rc = fail(rcu, "one-shot pipeline: waiting for a chunk's device-to-host copy failed");
+    } else {
+        for (int c = std::max(0, enq - D); c < enq && rc == IRB_OK; c++) rc = unpack(c);
+    }
+    if (rc != IRB_OK) {                               // nothing of a failed call may still be writing the staging
+        (void) irb_sync(h);
+        (void) hipStreamSynchronize(g.s_in);
+        (void) hipStreamSynchronize(g.s_out);
+        return rc;
+    }
+    prof.total_ms = now_ms() - t_begin;
+    prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms; prof.wait_ms = wait_ms;
+    prof.h2d_ms = device_times && mode == 0 ? h2d_ms : -1.0; prof.kernels_ms = device_times ? kern_ms : -1.0; prof.d2h_ms = device_times && mode == 0 ? d2h_ms : -1.0;
+    prof.chunks = nc; prof.blocks_per_chunk = chunk_pref; prof.last_chunk_blocks = Tneed; prof.steps = (int) steps;
+    prof.slots = D; prof.zero_copy = mode == 1; prof.helper_thread = use_helper;
+    prof.mac_on_matrix_cores = use_mfma(h, chunk_blocks(0)) ? 1 : 0;
+    g.prof = prof; g.have_prof = true;
     return rc;
+}
+
+int irb_device_quiet_begin(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(IRB_ERR_ARG, "device %d out of range", device);
+    quiet_begin(device);
+    return IRB_OK;
+}
+
+int irb_device_quiet_end(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(IRB_ERR_ARG, "device %d out of range", device);
+    if (!device_quiet(device)) return fail(IRB_ERR_STATE, "irb_device_quiet_end without a matching begin");
+    quiet_end(device);
+    return IRB_OK;
+}
+
+int irb_convolve_profile_events(int on)
+{
+    const int was = g_offline_profile_events ? 1 : 0;
+    g_offline_profile_events = on != 0;
+    return was;
+}
+
+int irb_convolve_last_profile(irb_convolve_profile *out)
+{
+    if (!out) return fail(IRB_ERR_ARG, "null argument");
+    if (!g_offline.have_prof) return fail(IRB_ERR_STATE, "no irb_convolve_periodic call has completed on this thread");
+    *out = g_offline.prof;
+    return IRB_OK;
 }
 
 // ---- several GPUs from one host process ------------------------------------------------------------------

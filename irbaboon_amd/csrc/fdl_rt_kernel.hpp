@@ -191,17 +191,26 @@ __global__ __launch_bounds__(kThreads) void k_rt_pair(StepArgs a)
 // inputs and IR partitions first, then {n_blocks, first_partition, head}, a store fence, then the request number.  Thread 0
 // polls the request number with system-scope loads (s_sleep between polls); the workgroup runs rt_blocks and answers with
 // the same completion word as k_rt_pair.  Every wave reaches an exit: a quit word (the host stops the server before any
-// other call touches the engine), an idle timeout (no request for idle_ticks of the 100 MHz clock: the transport stopped),
-// and a lifetime cap.  The kernel's last act is a system-scope store of its generation to `exited`: a host that posted a
+// other call touches the engine), a yield word (another thread of the process is about to make a device-synchronising runtime
+// call -- hipFree, hipDeviceSynchronize -- which would otherwise wait for this kernel: irb_device_quiet_begin), an idle timeout
+// (no request for idle_ticks of the 100 MHz clock: the transport stopped), and a lifetime cap (250 ms: the longest a FOREIGN
+// device-wide wait can be held up).  The kernel's last act is a system-scope store of its generation to `exited`: a host that posted a
 // request while the server was on its way out sees that word with the request unanswered and launches the next
 // generation, whose first request it is -- a request is therefore served exactly once.
 // ---------------------------------------------------------------------------------------------
-struct RtMailbox {
+struct alignas(64) RtMailbox {
     unsigned seq;                                      // request number, written LAST by the host
     int      n_blocks, first_partition, head;
-    unsigned quit;
-    unsigned pad[11];
+    union {
+        struct {
+            unsigned quit;                             // the handle's own thread: leave now (it then waits for the kernel)
+            unsigned yield;                            // any thread of the process (irb_device_quiet_begin): leave after the request in hand
+        };
+        unsigned long long leave;                      // both, as the server polls them: one 8-byte load
+    };
+    unsigned pad[10];
 };
+static_assert(sizeof(RtMailbox) == 64 && offsetof(RtMailbox, leave) == 16, "one cache line; quit and yield share an aligned 8-byte word");
 
 template <int N, int NCH = 2>
 __global__ __launch_bounds__(kThreads) void k_rt_server(StepArgs a, const RtMailbox *mb, unsigned *exited, unsigned gen,
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_rt_server(StepArgs a, const RtMail
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             for (;;) {
                 if (__hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == next) { cmd = 1; break; }
-                if (__hip_atomic_load(&mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+                if (__hip_atomic_load(&mb->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // quit | yield
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (now - t0 > idle_ticks || now - born > life_ticks) break;
                 __builtin_amdgcn_s_sleep(4);

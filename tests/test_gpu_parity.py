@@ -377,6 +377,98 @@ def test_resident_server_yields_to_every_other_entry_point():
     assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
 
 
+def test_resident_server_does_not_stall_other_handles():
+    """A live k_rt_server holds its stream for as long as callbacks keep coming, and hipFree / hipHostFree wait for every stream of
+    the device.  Adapter A streams 256-sample callbacks from its own thread (default: resident server) while the main thread does
+    what a second plug-in instance and an offline tool do in the same process: releaseResources + prepareToPlay on adapter B
+    (Source/PluginProcessor.cpp:164-248) several times, one convolvePeriodic that has to build its engine and one that
+    releases it again.  None of it may wait for A's server (the library brackets its device-wide waits with quiet sections:
+    the server steps aside, A's callbacks take the one-launch form meanwhile), and A's samples must be those of the
+    restated processBlock throughout.  The measured times go to gpurun_out/resident_vs_process.txt."""
+    import threading
+    import time
+    import irbaboon_amd
+    ir = decaying_ir(5, 8 * 256)
+    n_cb = 6000
+    x = np.stack([white_noise(47, n_cb * 256), white_noise(48, n_cb * 256)])
+    A = RtConvolver(2, 256, 2048)
+    A.prepareToPlay(256)
+    A.setIR(ir)
+    Bc = RtConvolver(2, 256, 2048)
+    Bc.prepareToPlay(256)
+    stop, done_cb, cb_ms, y = threading.Event(), [0], [], np.zeros_like(x)
+    errs = []
+
+    def audio_thread():
+        try:
+            for k in range(n_cb):
+                if stop.is_set():
+                    break
+                blk = np.ascontiguousarray(x[:, k * 256:(k + 1) * 256])
+                t0 = time.perf_counter()
+                A.processBlock(blk)
+                cb_ms.append((time.perf_counter() - t0) * 1e3)
+                y[:, k * 256:(k + 1) * 256] = blk
+                done_cb[0] = k + 1
+        except Exception as e:                                   # noqa: BLE001 -- reported by the main thread
+            errs.append(e)
+
+    th = threading.Thread(target=audio_thread)
+    th.start()
+    while done_cb[0] < 200 and th.is_alive():                    # the server is up and in its steady state
+        time.sleep(0.001)
+    c0 = A.counters()
+    marks = {}
+    xs, hs = white_noise(49, 48000)[None], decaying_ir(50, 12000)[None]
+    t0 = time.perf_counter()
+    for _ in range(3):
+        Bc.releaseResources()
+        Bc.prepareToPlay(256)
+    marks["3x B.releaseResources + B.prepareToPlay"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    yo = convolvePeriodic(xs, hs, 256)                           # builds the calling thread's engine (hipMalloc, hipHostMalloc, streams)
+    marks["convolvePeriodic (engine built)"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    irbaboon_amd.lib().irb_release_cached_plans()                # ... and frees it (hipFree, hipHostFree)
+    marks["irb_release_cached_plans"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with FdlEngine(4, 1, 256, 24000) as e2:                      # an unrelated engine: create, one step, destroy
+        e2.set_ir(0, hs[0])
+        e2.process(xs[:, :256].repeat(4, axis=0))
+    marks["FdlEngine create + step + destroy"] = time.perf_counter() - t0
+    cb_during = done_cb[0]
+    time.sleep(0.05)                                             # A goes back to the resident form
+    c1 = A.counters()
+    stop.set()
+    th.join(timeout=60)
+    assert not th.is_alive() and not errs, errs
+    n_done = done_cb[0]
+    Bc.close()
+    A.close()
+    ref = oracle.RtProcessor(2, 256, 2048)
+    ref.prepare_to_play(256)
+    ref.set_ir(ir)
+    yr = np.empty_like(x[:, :n_done * 256])
+    for k in range(n_done):
+        b = np.ascontiguousarray(x[:, k * 256:(k + 1) * 256])
+        ref.process_block(b)
+        yr[:, k * 256:(k + 1) * 256] = b
+    for c in range(2):
+        assert rel_rms(y[c, :n_done * 256], yr[c]) < RMS_TOL
+    assert rel_rms(yo[0], direct_f64(xs, hs)[0]) < RMS_TOL
+    cb = np.array(cb_ms)
+    lines = [f"{k}: {v * 1e3:.2f} ms" for k, v in marks.items()]
+    lines.append(f"adapter A: {n_done} callbacks of 256 samples ({cb_during - 200} of them while the main thread worked), median {np.median(cb) * 1e3:.1f} us, "
+                 f"p99 {np.percentile(cb, 99) * 1e3:.1f} us, max {cb.max() * 1e3:.1f} us; launches in that window {c1[1] - c0[1]}, waits {c1[2] - c0[2]}")
+    os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "resident_vs_process.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    # a stall behind the server would be its lifetime cap (250 ms) per device-wide wait: dozens of frees -> seconds
+    assert sum(marks.values()) < 1.5, marks
+    assert cb.max() < 100.0, cb.max()                            # ms: no callback was held up for a server lifetime either
+
+
 def test_rt_adapter_host_block_larger_than_block_is_causal():
     """hostBlock 512 > 256: the reference's FDL ring is one slot short and feeds a future block to
     its last partition; the adapter keeps P past blocks, so it must equal the true
