@@ -225,12 +225,15 @@ typedef struct irb_convolve_profile {
     double total_ms;            /* the whole call                                                           */
     double setup_ms;            /* engine look-up (or creation: engine_created), FDL reset, IR upload + transform enqueued */
     double pack_ms;             /* calling thread: caller's audio -> pinned staging                         */
-    double unpack_ms;           /* unpacking thread (or the calling thread): pinned staging -> caller's out */
-    double wait_ms;             /* the unpacking side blocked on the chunks' completion events              */
-    double stall_ms;            /* the calling thread blocked on the unpacking side (slot reuse, end of call) */
-    double h2d_ms, kernels_ms, d2h_ms;   /* device: copy queue in, the three kernels per chunk, copy queue out */
-    int chunks, blocks_per_chunk, last_chunk_blocks, steps;     /* steps = floor(La/B) + P (+1 without the reference's dropped tail) */
-    int slots, zero_copy, helper_thread, engine_created, mac_on_matrix_cores;
+    double unpack_ms;           /* calling thread: pinned staging -> caller's out (its share of the chunks) */
+    double unpack_helper_ms;    /* unpacking thread: the same for the other chunks                          */
+    double wait_ms;             /* calling thread blocked on output chunks' events                          */
+    double wait_helper_ms;      /* unpacking thread blocked on output chunks' events                        */
+    double stall_ms;            /* calling thread waiting for the unpacking thread at the end               */
+    double fft_in_and_mac_ms;   /* device: first forward-FFT launch -> multiply done (includes waiting for the host's packing) */
+    double fft_out_ms;          /* device: inverse FFTs + overlap-add of all chunks                          */
+    int chunks, blocks_per_chunk, pieces, steps;   /* steps = floor(La/B) + P (+1 without the reference's dropped tail); pieces = multiplies */
+    int helper_thread, engine_created, mac_on_matrix_cores, mac_launches;
 } irb_convolve_profile;
 int  irb_convolve_last_profile(irb_convolve_profile *out);
 /* switch the device-event part of the profile on / off for the whole process; returns the previous setting (measurement

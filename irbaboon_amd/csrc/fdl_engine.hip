@@ -64,6 +64,7 @@ struct irb_fdl {
     int mfma_min_T = 512;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
     int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
+    bool mfma_two_launch = true;             // whole rounds of workgroups + a second launch for the remaining tiles (IRB_TILED_MFMA_TWO_LAUNCH)
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
@@ -93,6 +94,10 @@ struct irb_fdl {
     long long t = 0;                         // block steps done since reset
     size_t bytes = 0;
 
+    // matrix-core path of long calls (fdl_mfma.hpp): the FDL and the IR spectra a second time, time / tap contiguous per bin
+    bool mfma_capable = false;               // this handle's longest call multiplies on the matrix cores: d_Xt / d_Ht exist
+    float2 *d_Xt = nullptr, *d_Ht = nullptr; // [S][M][xt_len], [S][M][ht_len]
+    int xt_len = 0, xt_hist = 0, ht_len = 0;
     float2 *d_H = nullptr, *d_X = nullptr, *d_tw = nullptr, *d_part = nullptr;
     float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
     int2 *d_stream_info = nullptr;          // [S] {IR set, partitions in use}: what the kernels read
@@ -254,28 +259,39 @@ int tiled_splits(const irb_fdl *h, int T)
 // long calls: the Toeplitz-block MAC on the matrix cores (fdl_mfma.hpp)
 bool use_mfma(const irb_fdl *h, int T)
 {
-    // (its buffer descriptors address a stream's FDL ring and an IR set with 31-bit byte offsets)
-    const size_t row = (size_t) h->M * sizeof(float2);
-    // gfx950 only: 141 KiB of LDS per workgroup, descriptor word and instruction timings are that chip's
-    return h->is_gfx950 && h->mfma_min_T > 0 && T >= h->mfma_min_T && h->M % irb::kMfmaBins == 0 && (size_t) h->R * row < (1u << 31) && (size_t) h->Ppad * row < (1u << 31);
+    return h->mfma_capable && T >= h->mfma_min_T;        // (mfma_capable: gfx950, not stepwise, the handle's longest call qualifies; set at create)
 }
 
-// k_cmac_mfma keeps two stage images in LDS (141 KiB): beyond the 64 KiB a kernel gets without asking
-int mfma_prepare(const irb_fdl *h)
-{
-    FOR_N(h->N, HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&irb::k_cmac_mfma<NN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) irb::kMfmaLds)));
-    return IRB_OK;
-}
+// How a call of T blocks is multiplied there.  A workgroup = one 256-block tile x 16 bins x one range of Toeplitz chunks and there
+// is one workgroup per CU at a time, so the grid should be whole rounds of (at most) mfma_wgs workgroups: a call whose tiles do
+// not fill a whole number of rounds is multiplied in TWO launches -- the full rounds unsplit (region A of the partial spectra,
+// one row per block), then the remaining tiles with their partitions split over the idle CUs (region B, nqB rows per block).
+// (configs[1] one-shot: 4125 blocks = 17 tiles x 16 bin groups = 272 workgroups on 256 CUs would take two rounds for 6 % more
+// work than one; as 16 + 1 tiles the second launch is 64 workgroups of a quarter of the partitions each.)
+struct MfmaPlan {
+    int tilesA = 0, splitsA = 1, tilesB = 0, splitsB = 1;
+    int t_split(int T) const { return tilesB > 0 ? tilesA * irb::kMfmaTile : T; }          // blocks below it: region A
+    size_t part_rows(int S, int T) const { return (size_t) S * ((size_t) t_split(T) * splitsA + (size_t) (T - t_split(T)) * splitsB); }
+};
 
-// its partition splits: whole multiples only while the tiles x bin groups leave at least half of the CUs without a workgroup (a
-// split adds a partial spectrum per output; 240 workgroups on 256 CUs are faster unsplit: profiles/r03_mfma_ab.txt), every split
-// at least one LDS stage of chunks
-int mfma_splits(const irb_fdl *h, int T)
+MfmaPlan mfma_plan(const irb_fdl *h, int T)
 {
-    const long wgs = (long) h->S * ((T + irb::kMfmaTile - 1) / irb::kMfmaTile) * (h->M / irb::kMfmaBins);
-    const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);
-    const int by_chip = (int) std::max<long>(1, h->mfma_wgs / wgs);
-    return std::max(1, std::min(by_work, by_chip));
+    MfmaPlan p;
+    const int ntiles = (T + irb::kMfmaTile - 1) / irb::kMfmaTile;
+    const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
+    const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);           // every split keeps a few chunks
+    auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, h->mfma_wgs / std::max<long>(1, wgs))); };
+    const long per_round = h->mfma_wgs / units;                                              // tiles that fill the chip once
+    const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
+    if (full == 0 || full == ntiles || !h->mfma_two_launch) {
+        p.tilesA = ntiles;
+        p.splitsA = ntiles * units < h->mfma_wgs ? splits_for(ntiles * units) : 1;
+        return p;
+    }
+    p.tilesA = full;
+    p.tilesB = ntiles - full;
+    p.splitsB = splits_for(p.tilesB * units);
+    return p;
 }
 
 irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long stride)
@@ -283,6 +299,9 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     irb::StepArgs a;
     a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
+    a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len;
+    a.tile_first = 0; a.tile_count = 1; a.t_base = 0; a.part_T = 1;
+    a.t_first = 0; a.t_count = 1; a.part2 = nullptr; a.t_split = 1; a.nq2 = 1;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
@@ -349,48 +368,131 @@ int launch_step(irb_fdl *h, const irb::StepArgs &a)
     return IRB_OK;
 }
 
-// T > 1 blocks of every stream in three launches (see fdl_kernels.hpp, time-tiled path)
-int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
+// ---- T > 1 blocks of every stream (see fdl_kernels.hpp, time-tiled path; fdl_mfma.hpp) -------------------------------------
+// Three phases, each able to work on a sub-range of the call's blocks so that irb_convolve_periodic can move a signal in and out
+// in chunks around ONE multiply over all of its blocks: forward FFTs of blocks [first, first + count), the multiply-accumulate
+// of all T outputs, inverse FFTs + overlap-add of blocks [first, first + count).
+struct TiledCall {
+    irb::StepArgs a;
+    int T = 0, tt = 0, ntiles = 0;
+    bool mfma = false, one_bin = false;
+    MfmaPlan plan;
+};
+
+int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     a.T = T;
     a.splits = tiled_splits(h, T);
     a.nq = a.splits * stripes;
     a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
+    a.t_first = 0; a.t_count = T; a.t_split = T; a.part2 = nullptr; a.nq2 = 1; a.part_T = T; a.t_base = 0;
+    c->T = T;
     // one complex bin per lane, 16 outputs per tile: fewer bytes per FMA.  Pays when the rows come from HBM (working
     // set beyond the Infinity Cache) and the call is long enough; cache-resident calls are faster with k_cmac_tiled
-    const bool mfma = use_mfma(h, T);
-    const bool one_bin = !mfma && h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
+    c->mfma = use_mfma(h, T);
+    c->one_bin = !c->mfma && h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
-    if (mfma) { a.splits = mfma_splits(h, T); a.nq = a.splits; }
-    else if (one_bin) a.nq = a.splits * stripes1;
-    else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
-    if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
-    const int tt = tile_outputs(h, T);
-    const int ntiles = one_bin ? (T + 15) / 16 : (T + tt - 1) / tt;
-    const dim3 mac_grid(h->S * ntiles * a.splits), mac_block(irb::kThreads);
-    h->n_launches += 3;
-    FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * T + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
-    // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
-    const bool nt1 = h->nt && ntiles == 1;
-    if (mfma) {
-        const dim3 grid(h->S * ((T + irb::kMfmaTile - 1) / irb::kMfmaTile) * a.splits * (h->M / irb::kMfmaBins));
-        FOR_N(h->N, irb::k_cmac_mfma<NN><<<grid, dim3(irb::kMfmaThreads), irb::kMfmaLds, h->stream>>>(a));
+    if (c->mfma) {
+        c->plan = mfma_plan(h, T);
+        a.splits = c->plan.splitsA; a.nq = c->plan.splitsA;
+        a.t_split = c->plan.t_split(T);
+        a.nq2 = c->plan.splitsB;
+        a.part2 = h->d_part + (size_t) h->S * a.t_split * a.nq * h->M;
+        if (c->plan.part_rows(h->S, T) > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
     }
-    else if (one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (c->one_bin) a.nq = a.splits * stripes1;
+    else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
+    if (!c->mfma && (size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
+    c->tt = tile_outputs(h, T);
+    c->ntiles = c->one_bin ? (T + 15) / 16 : (T + c->tt - 1) / c->tt;
+    c->a = a;
+    if (c->mfma && h->t > 0) {
+        // the call continues a stream: the blocks before its first one go from the ring into Xt's history columns
+        int first = (int) ((h->t - h->xt_hist) % h->R);
+        if (first < 0) first += h->R;
+        h->n_launches++;
+        const dim3 grid(h->xt_hist / 16, h->M >= 64 ? h->M / 64 : 1, h->S);
+        FOR_N(h->N, irb::k_rows_to_columns<NN / 2><<<grid, dim3(256), 0, h->stream>>>(h->d_X, (long) h->R * h->M, first, h->R, h->xt_hist,
+                                                                                       h->d_Xt, (long) h->M * h->xt_len, h->xt_len, 0, h->xt_hist));
+        HIP_TRY(hipGetLastError());
+    }
+    return IRB_OK;
+}
+
+int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
+{
+    irb::StepArgs a = c.a;
+    a.t_first = first; a.t_count = count;
+    h->n_launches++;
+    if (c.mfma) {
+        FOR_N(h->N, irb::k_push_fft_batch_t<NN><<<dim3(h->S * ((count + irb::PushTGeom<NN>::NBW - 1) / irb::PushTGeom<NN>::NBW)),
+                                                  dim3(irb::kWave * irb::PushTGeom<NN>::NBW), 0, h->stream>>>(a, h->S));
+    } else {
+        FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * count + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
+    }
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+int tiled_mac(irb_fdl *h, const TiledCall &c)
+{
+    irb::StepArgs a = c.a;
+    const int T = c.T;
+    const dim3 mac_grid(h->S * c.ntiles * a.splits), mac_block(irb::kThreads);
+    // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
+    const bool nt1 = h->nt && c.ntiles == 1;
+    h->n_launches++;
+    if (c.mfma) {
+        const int groups = h->M / irb::kMfmaBins;
+        a.tile_first = 0; a.tile_count = c.plan.tilesA; a.t_base = 0; a.part_T = a.t_split;
+        FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * c.plan.tilesA * c.plan.splitsA * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        if (c.plan.tilesB > 0) {
+            h->n_launches++;
+            a.tile_first = c.plan.tilesA; a.tile_count = c.plan.tilesB; a.t_base = a.t_split; a.part_T = T - a.t_split;
+            a.splits = c.plan.splitsB; a.nq = c.plan.splitsB; a.part = const_cast<float2 *>(a.part2);
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * c.plan.tilesB * c.plan.splitsB * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        }
+    }
+    else if (c.one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (h->tiled_kernel == 0) {
         if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
         else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     }
-    else if (tt == 8 && nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    else if (tt == 8)        { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (c.tt == 8 && nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
+    else if (c.tt == 8)        { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else          { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((T + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+int tiled_ifft(irb_fdl *h, const TiledCall &c, int first, int count)      // first: a multiple of OlaGeom::NB
+{
+    irb::StepArgs a = c.a;
+    a.t_first = first; a.t_count = count;
+    h->n_launches++;
+    FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((count + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
                                                                  dim3(irb::kWave * (irb::OlaGeom<NN>::NB + 1)), 0, h->stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
-    h->ovl_cur ^= 1;
     return IRB_OK;
+}
+
+void tiled_end(irb_fdl *h, const TiledCall &c)
+{
+    h->ovl_cur ^= 1;
+    h->t += c.T;
+}
+
+int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
+{
+    TiledCall c;
+    int rc = tiled_begin(h, a, T, &c);
+    if (rc == IRB_OK) rc = tiled_push(h, c, 0, T);
+    if (rc == IRB_OK) rc = tiled_mac(h, c);
+    if (rc == IRB_OK) rc = tiled_ifft(h, c, 0, T);
+    if (rc == IRB_OK) h->ovl_cur ^= 1;                    // (h->t is advanced by the caller, as for one-block steps)
+    return rc;
 }
 
 int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int first_set, int first_partition)
@@ -399,6 +501,20 @@ int launch_ir_fft(irb_fdl *h, const float *d_ir, int nparts, int nrows, int firs
     FOR_N(h->N, irb::k_ir_fft<NN><<<dim3((nparts * nrows + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF),
                                      dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(
                     d_ir, h->d_H, h->d_tw, h->B, h->Ppad, first_set, first_partition, nparts, nrows));
+    HIP_TRY(hipGetLastError());
+    return IRB_OK;
+}
+
+// the IR sets [first_set, first_set + nsets) once more with the tap index contiguous per bin (fdl_mfma.hpp); np rows of each are
+// taps, everything behind them zeros
+int launch_ht(irb_fdl *h, int first_set, int nsets, int np)
+{
+    if (!h->d_Ht || nsets < 1) return IRB_OK;
+    h->n_launches++;
+    const int nrows = h->ht_len - 16;
+    const dim3 grid(nrows / 16, h->M >= 64 ? h->M / 64 : 1, nsets);
+    FOR_N(h->N, irb::k_rows_to_columns<NN / 2><<<grid, dim3(256), 0, h->stream>>>(h->d_H + (size_t) first_set * h->Ppad * h->M, (long) h->Ppad * h->M, 0, 0, np,
+                                                                                   h->d_Ht + (size_t) first_set * h->M * h->ht_len, (long) h->M * h->ht_len, h->ht_len, 16, nrows));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
@@ -585,38 +701,29 @@ struct Unpacker {
 };
 
 struct OfflineEngineGuard {
-    irb_fdl *eng = nullptr;
-    int D = 0;                                         // staging slots (chunks in flight)
-    size_t half = 0;                                   // floats per slot half (input or output): C * Tmax * B
-    float *stage = nullptr, *d_stage = nullptr;        // pinned [D][input | output][C][Tmax*B] and its device address (mapped)
-    float *d_io = nullptr;                             // device  [D][input | output][C][Tmax*B] (copy mode)
-    hipStream_t s_in = nullptr, s_out = nullptr;       // H2D and D2H queues beside the engine's own stream
-    // per slot: [0] before H2D, [1] H2D done, [2] kernels done, [3] D2H done (timing enabled: the profile reads them)
-    std::vector<hipEvent_t> ev;
+    irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
+    std::vector<hipEvent_t> ev;                        // [0..2]: first FFT launch, multiply done, (unused); [3 + k]: output chunk k has left
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
     void release()
     {
         unpacker.stop();
-        if (!eng) return;                              // (everything else is created together with the engine)
+        if (!eng) return;
         DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
         (void) hipSetDevice(eng->device);
         (void) irb_sync(eng);
-        if (s_in) { (void) hipStreamSynchronize(s_in); (void) hipStreamDestroy(s_in); s_in = nullptr; }
-        if (s_out) { (void) hipStreamSynchronize(s_out); (void) hipStreamDestroy(s_out); s_out = nullptr; }
-        if (eng) { irb_fdl_destroy(eng); eng = nullptr; }
-        if (stage) { (void) hipHostFree(stage); stage = nullptr; d_stage = nullptr; }
-        if (d_io) { (void) hipFree(d_io); d_io = nullptr; }
+        irb_fdl_destroy(eng);
+        eng = nullptr;
         for (auto &e : ev) if (e) (void) hipEventDestroy(e);
         ev.clear();
-        D = 0; half = 0;
     }
     ~OfflineEngineGuard() { release(); }
 };
 thread_local OfflineEngineGuard g_offline;
 std::atomic<bool> g_offline_profile_events{false};     // irb_convolve_profile_events(): read the chunks' device events into the profile
-constexpr int kOfflineChunk = 1024;                       // blocks per chunk of irb_convolve_periodic (IRB_OFFLINE_CHUNK); see profiles/r04_oneshot_sweep.txt
+constexpr int kOfflineChunk = 1024;                       // blocks per input / output chunk of irb_convolve_periodic (IRB_OFFLINE_CHUNK); profiles/r04_oneshot_sweep.txt
+constexpr int kOfflineMaxBlocks = 16384;                  // blocks per multiply: longer signals go through in several (the FDL carries over)
 }
 
 extern "C" {
@@ -634,6 +741,7 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->stream) (void) irb_sync(h);
     DeviceQuiet quiet(h->device);                        // the frees below wait for every stream of the device: other instances' servers step aside
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
+    (void) hipFree(h->d_Xt); (void) hipFree(h->d_Ht);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
     if (h->h_status) (void) hipHostFree(h->h_status);
@@ -697,6 +805,14 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 512));
     h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
     h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
+    h->mfma_two_launch = env_int("IRB_TILED_MFMA_TWO_LAUNCH", 1) != 0;
+    // gfx950 only: the instruction timings and the DPP / buffer-load forms the kernel is written in are that chip's
+    h->mfma_capable = h->is_gfx950 && !h->stepwise && h->mfma_min_T > 0 && h->Tmax >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
+    if (h->mfma_capable) {
+        h->xt_hist = irb::mfma_hist(h->P);
+        h->xt_len = h->xt_hist + (h->Tmax + irb::kMfmaTile - 1) / irb::kMfmaTile * irb::kMfmaTile;
+        h->ht_len = irb::mfma_taps(h->P);
+    }
     // resident workgroups of the MAC kernel: 256 CUs x waves per SIMD its registers allow (2 / 2 / 3 / 4); round 2: 768 as a floor
     const int slots[2] = {768, 512};
     h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", slots[h->tiled_kernel]));
@@ -713,16 +829,17 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventCreate failed"); break; }
         if (rc != IRB_OK) break;
         const size_t SM = (size_t) h->S * h->M;
-        if (!h->stepwise && use_mfma(h, h->Tmax) && !guard(mfma_prepare(h))) break;
         if (!guard(dev_alloc(h, &h->d_H, SM * h->Ppad + (size_t) 8 * h->M))) break;     // + spare rows: the tiled MAC's last prefetch reads past the last set
         if (!guard(dev_alloc(h, &h->d_X, SM * h->R))) break;
         if (!guard(dev_alloc(h, &h->d_tw, (size_t) h->N))) break;
+        if (h->mfma_capable && !guard(dev_alloc(h, &h->d_Xt, SM * h->xt_len))) break;
+        if (h->mfma_capable && !guard(dev_alloc(h, &h->d_Ht, SM * h->ht_len))) break;
         {
             const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
             size_t rows = (size_t) h->S * std::max(h->splits, 1);
             for (int T = 2; T <= h->Tmax && !h->stepwise; T++) {
-                rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
-                if (use_mfma(h, T)) rows = std::max(rows, (size_t) h->S * T * mfma_splits(h, T));
+                if (use_mfma(h, T)) rows = std::max(rows, mfma_plan(h, T).part_rows(h->S, T));
+                else rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
             }
             h->part_rows = rows;
         }
@@ -756,7 +873,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         }
         *h->h_status = 0;
         *h->h_done = 0;
-        if (h->host_io && env_int("IRB_RT_BAR", 1)) {
+        if (h->host_io && h->stepwise && env_int("IRB_RT_BAR", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
                 const size_t nin = ((size_t) h->S * h->Tmax * h->B + 15) / 16 * 16, nir = ((size_t) h->P * h->B + 15) / 16 * 16;
@@ -790,6 +907,8 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if ((e = hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * h->N, hipMemcpyHostToDevice)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_H, 0, sizeof(float2) * (SM * h->Ppad + (size_t) 8 * h->M), h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
+            (h->d_Xt && (e = hipMemsetAsync(h->d_Xt, 0, sizeof(float2) * SM * h->xt_len, h->stream)) != hipSuccess) ||
+            (h->d_Ht && (e = hipMemsetAsync(h->d_Ht, 0, sizeof(float2) * SM * h->ht_len, h->stream)) != hipSuccess) ||
             (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * (size_t) h->S, h->stream)) != hipSuccess ||
             (h->d_gran && (e = hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream)) != hipSuccess) ||
@@ -872,6 +991,7 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
     for (int r = 0; r < nrows && np_pad > np; r++)
         HIP_TRY(hipMemsetAsync(h->d_H + ((size_t) (first_set + r) * h->Ppad + np) * h->M, 0,
                                sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
+    { int rc = launch_ht(h, first_set, nrows, np); if (rc != IRB_OK) return rc; }
     int2 *info = h->h_info_slot + (size_t) slot * h->C;
     for (int c = 0; c < h->C; c++) {
         h->h_set_of_stream[first_set + c] = first_set + (nrows == 2 ? c : 0);   // fp/convolution.cpp:176-181
@@ -916,6 +1036,8 @@ int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const floa
         rc = launch_ir_fft(h, ds, 1, 1, first_set, partition);
     }
     if (rc != IRB_OK) return rc;
+    rc = launch_ht(h, first_set, 1, h->P);                           // (engines that take long calls only: the plug-in's are stepwise)
+    if (rc != IRB_OK) return rc;
     bool changed = false;
     for (int c = 0; c < h->C; c++) {
         if (h->h_set_of_stream[first_set + c] != first_set || h->h_np_of_set[first_set + c] != h->P) changed = true;
@@ -958,6 +1080,7 @@ int irb_fdl_set_ir_spectra(irb_fdl *h, int instance, const float *const *spectra
         const int np_pad = std::min((np + kPadP - 1) / kPadP * kPadP, h->Ppad);
         if (np_pad > np) HIP_TRY(hipMemsetAsync(dst + (size_t) np * h->M, 0, sizeof(float2) * (size_t) (np_pad - np) * h->M, h->stream));
     }
+    { int rc = launch_ht(h, first_set, ir_channels, np); if (rc != IRB_OK) return rc; }
     for (int c = 0; c < h->C; c++) {
         h->h_set_of_stream[first_set + c] = first_set + (ir_channels == 2 ? c : 0);
         h->h_np_of_set[first_set + c] = np;
@@ -975,6 +1098,8 @@ int irb_fdl_reset(irb_fdl *h)
     STOP_SERVER(h);
     HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream));
+    if (h->d_Xt)                                    // the blocks "before" the next call: zero, like the ring (the columns of the calls themselves are rewritten by every call)
+        HIP_TRY(hipMemset2DAsync(h->d_Xt, sizeof(float2) * h->xt_len, 0, sizeof(float2) * h->xt_hist, (size_t) h->S * h->M, h->stream));
     if (h->d_gran)                                  // the step counter restarts, and with it the granule tags
         HIP_TRY(hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream));
     h->t = 0;
@@ -1319,164 +1444,142 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     const long lim = keep_reference_tail ? std::min<long>(Lout, written) : Lout;    // samples this call produces (:225-227)
     clear_out(lim);                                                                 // the dropped tail stays 0 (:236-238)
 
-    // ---- the chunk pipeline ---------------------------------------------------------------------------------------------
-    // The signal goes through in chunks of whole 256-block tiles of the matrix-core MAC (all but the last chunk; the last one
-    // takes the remainder, so no chunk is shorter than IRB_OFFLINE_CHUNK blocks unless the whole call is), D staging slots deep:
-    //   calling thread : pack chunk c into pinned memory, enqueue H2D (own queue) -> kernels (engine's stream) -> D2H (own queue)
-    //   unpacking thread: wait for chunk c's D2H, copy its samples to the caller's buffer
-    // so the two host copies (most of a call's time), the three PCIe/compute queues and nothing else overlap.
+    // ---- the pipeline ---------------------------------------------------------------------------------------------------
+    // ONE multiply-accumulate over all blocks of the signal (the shape the matrix-core kernel is best at: every IR tap is loaded
+    // once per 256 outputs), with the signal moved in and out in chunks around it:
+    //   calling thread : pack chunk k of the audio into pinned memory, launch the forward FFTs of its blocks (the kernel reads the
+    //                    pinned staging over PCIe, no copy command) ... launch the multiply ... launch the inverse FFTs + overlap-add
+    //                    of chunk k (the kernel writes the pinned staging) + an event, for every k
+    //   both threads   : wait for chunk k's event, copy its samples to the caller's buffer (even chunks here, odd chunks on the
+    //                    unpacking thread: that copy is the longest single item of a call)
+    // Signals of more than kOfflineMaxBlocks blocks repeat this per piece; the FDL (ring and overlap) carries over.
     const double t_begin = now_ms();
     irb_convolve_profile prof;
     std::memset(&prof, 0, sizeof prof);
-    const int chunk_pref = std::max(1, (env_int("IRB_OFFLINE_CHUNK", kOfflineChunk) + 255) / 256 * 256);
-    const int nc = (int) std::max<long>(1, steps / chunk_pref);
-    auto chunk_first = [&](int c) { return (long) c * chunk_pref; };
-    auto chunk_blocks = [&](int c) { return (int) (c == nc - 1 ? steps - chunk_first(c) : chunk_pref); };
-    const int Tneed = chunk_blocks(nc - 1);                                          // the longest chunk (< 2 * chunk_pref)
-    const int mode = env_int("IRB_OFFLINE_MODE", 0);                                 // 0 staged copies, 1 zero copy (kernels read / write the pinned staging)
-    const bool use_helper = env_int("IRB_OFFLINE_HELPER", 1) != 0 && nc > 1;
+    const int io = std::max(16, (env_int("IRB_OFFLINE_CHUNK", kOfflineChunk) + 15) / 16 * 16);   // multiple of the FFT kernels' blocks per workgroup
+    const int Tneed = (int) std::min<long>(steps, kOfflineMaxBlocks);
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     irb_fdl *h = g_offline.eng;
-    const int Dwant = std::min(nc, std::max(2, env_int("IRB_OFFLINE_SLOTS", 4)));
-    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= Tneed && h->Tmax <= 8 * Tneed + 64 &&
-          g_offline.D >= Dwant)) {
+    if (!(h && h->device == device && h->C == audio_ch && h->B == B && h->P >= P && h->Tmax >= Tneed && h->Tmax <= 4 * Tneed + 1024)) {
         g_offline.release();
         irb_fdl_config cfg;
         std::memset(&cfg, 0, sizeof cfg);
         cfg.device = device; cfg.n_instances = 1; cfg.channels = audio_ch; cfg.block = B; cfg.max_ir_len = P * B;
-        cfg.max_blocks_per_call = nc > 1 ? 2 * chunk_pref - 1 : Tneed;              // any later call of this block size and IR length fits
+        cfg.max_blocks_per_call = Tneed < 512 ? Tneed : (Tneed + 1023) / 1024 * 1024;   // (a later call of this block size and IR length that is a little longer still fits)
+        cfg.flags = IRB_FDL_HOST_IO;
         int rc0 = irb_fdl_create(&cfg, &h);
         if (rc0 != IRB_OK) return rc0;
         g_offline.eng = h;
-        g_offline.D = nc > 1 ? std::max(Dwant, 4) : 1;
-        g_offline.half = (size_t) audio_ch * h->Tmax * B;
-        const size_t total = (size_t) g_offline.D * 2 * g_offline.half;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&g_offline.stage), sizeof(float) * total, hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&g_offline.d_stage), g_offline.stage, 0);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g_offline.d_io), sizeof(float) * total);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_in, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_out, hipStreamNonBlocking);
-        g_offline.ev.assign((size_t) g_offline.D * 4, nullptr);
-        for (auto &ev : g_offline.ev) if (e == hipSuccess) e = hipEventCreate(&ev);
-        if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline staging: %s", hipGetErrorString(e)); }
+        hipError_t e = hipSuccess;
+        g_offline.ev.assign((size_t) 3 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
+        for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
+        if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
     OfflineEngineGuard &g = g_offline;
-    const int D = g.D;
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
     rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
     if (rc != IRB_OK) return rc;
     const long stride = (long) h->Tmax * h->B;
-    auto ev_of = [&](int c, int k) { return g.ev[(size_t) (c % D) * 4 + k]; };
-    auto host_in = [&](int c) { return g.stage + (size_t) (c % D) * 2 * g.half; };
-    auto host_out = [&](int c) { return host_in(c) + g.half; };
-    auto dev_in = [&](int c) { return (mode == 1 ? g.d_stage : g.d_io) + (size_t) (c % D) * 2 * g.half; };
-    auto dev_out = [&](int c) { return dev_in(c) + g.half; };
+    float *const host_in = h->h_io, *const host_out = h->h_io + (size_t) audio_ch * stride;
+    float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
     prof.setup_ms = now_ms() - t_begin;
     const bool device_times = g_offline_profile_events;
-    double pack_ms = 0, unpack_ms = 0, wait_ms = 0, h2d_ms = 0, kern_ms = 0, d2h_ms = 0;     // unpack_*, wait_*, device times: written by the unpacking side only
+    const bool want_helper = env_int("IRB_OFFLINE_HELPER", 1) != 0;
+    double pack_ms = 0, unpack_ms[2] = {0, 0}, wait_ms[2] = {0, 0}, dev_ms[3] = {0, 0, 0};
+    int pieces = 0, nio_total = 0;
 
-    auto unpack = [&](int c) -> int {                                               // wait for chunk c, copy its samples out
-        const double t0 = now_ms();
-        hipError_t e = hipEventSynchronize(ev_of(c, 3));
-        if (e != hipSuccess) return fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-        const double t1 = now_ms();
-        const long s0 = chunk_first(c) * B, n = (long) chunk_blocks(c) * B;
-        const long take = std::max<long>(0, std::min<long>(n, lim - s0));
-        for (int ch = 0; ch < audio_ch; ch++)
-            if (take > 0) std::memcpy(out[ch] + s0, host_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) take);
-        if (device_times) {
-            float ms = 0;
-            if (mode == 0 && hipEventElapsedTime(&ms, ev_of(c, 0), ev_of(c, 1)) == hipSuccess) h2d_ms += ms;
-            if (hipEventElapsedTime(&ms, ev_of(c, 1), ev_of(c, 2)) == hipSuccess) kern_ms += ms;
-            if (mode == 0 && hipEventElapsedTime(&ms, ev_of(c, 2), ev_of(c, 3)) == hipSuccess) d2h_ms += ms;
-        }
-        wait_ms += t1 - t0;
-        unpack_ms += now_ms() - t1;
-        return IRB_OK;
-    };
-    if (use_helper) {
-        const int dev = device;
-        g.unpacker.begin(nc, [&, dev](int c) { (void) hipSetDevice(dev); return unpack(c); });
-    }
-    auto slot_is_free = [&](int c) -> int {                                          // chunk c - D has left the slot chunk c reuses
-        if (c < D) return IRB_OK;
-        if (!use_helper) return unpack(c - D);
-        const double t0 = now_ms();
-        while (g.unpacker.unpacked.load(std::memory_order_acquire) < c - D + 1) __builtin_ia32_pause();
-        prof.stall_ms += now_ms() - t0;
-        return g.unpacker.rc.load();
-    };
-    int enq = 0;
-    for (int c = 0; c < nc && rc == IRB_OK; c++) {
-        rc = slot_is_free(c);
-        if (rc != IRB_OK) break;
-        const int nb = chunk_blocks(c);
-        const long s0 = chunk_first(c) * B, n = (long) nb * B;
-        const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));      // samples of this chunk that hold audio
-        const long have_b = (have + B - 1) / B * B;                                  // ... rounded to whole blocks: what is copied; the flush blocks are zeroed on the device
-        const double t0 = now_ms();
-        for (int ch = 0; ch < audio_ch; ch++) {
-            float *dst = host_in(c) + (size_t) ch * stride;
-            if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
-            std::fill(dst + have, dst + (mode == 1 ? n : have_b), 0.0f);
-        }
-        pack_ms += now_ms() - t0;
-        hipError_t e = hipSuccess;
-        if (mode == 0) {
-            // the device slot is rewritten: the kernels of chunk c - D have read it (their event), and its output half has been copied out (D2H event)
-            if (c >= D) e = hipStreamWaitEvent(g.s_in, ev_of(c, 2), 0);
-            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 0), g.s_in);
-            for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++) {
-                if (have_b > 0) e = COPY_ASYNC(h, dev_in(c) + (size_t) ch * stride, host_in(c) + (size_t) ch * stride, sizeof(float) * (size_t) have_b,
-                                               hipMemcpyHostToDevice, g.s_in);
-                if (e == hipSuccess && n > have_b) e = hipMemsetAsync(dev_in(c) + (size_t) ch * stride + have_b, 0, sizeof(float) * (size_t) (n - have_b), g.s_in);
+    for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
+        const int T = (int) std::min<long>(Tneed, steps - p0);
+        const int nio = (T + io - 1) / io;
+        nio_total += nio;
+        for (int k = 0; k < nio; k++)
+            if (!g.ev[3 + k]) {
+                hipError_t e = hipEventCreateWithFlags(&g.ev[3 + k], hipEventDisableTiming);
+                if (e != hipSuccess) return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e));
             }
-            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 1), g.s_in);
-            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev_of(c, 1), 0);
-        } else {
-            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 1), h->stream);
+        TiledCall call;
+        bool tiled = T > 1;
+        irb::StepArgs a = step_args(h, dev_in, dev_out, stride);
+        if (tiled) { rc = tiled_begin(h, a, T, &call); if (rc != IRB_OK) break; }
+        if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
+        // ---- in: pack + forward FFTs, chunk by chunk
+        for (int k = 0; k < nio && rc == IRB_OK; k++) {
+            const int first = k * io, cnt = std::min(io, T - first);
+            const long s0 = (p0 + first) * B, n = (long) cnt * B;
+            const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));      // samples of this chunk that hold audio; the rest is the flush
+            const double t0 = now_ms();
+            for (int ch = 0; ch < audio_ch; ch++) {
+                float *dst = host_in + (size_t) ch * stride + (size_t) first * B;
+                if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
+                std::fill(dst + have, dst + n, 0.0f);
+            }
+            pack_ms += now_ms() - t0;
+            if (tiled) rc = tiled_push(h, call, first, cnt);
         }
-        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "H2D: %s", hipGetErrorString(e)); break; }
-        rc = irb_fdl_process_device(h, dev_in(c), dev_out(c), stride, nb);
         if (rc != IRB_OK) break;
-        e = hipEventRecord(ev_of(c, 2), h->stream);
-        if (mode == 0) {
-            if (e == hipSuccess) e = hipStreamWaitEvent(g.s_out, ev_of(c, 2), 0);
-            for (int ch = 0; ch < audio_ch && e == hipSuccess; ch++)
-                e = COPY_ASYNC(h, host_out(c) + (size_t) ch * stride, dev_out(c) + (size_t) ch * stride, sizeof(float) * (size_t) n,
-                               hipMemcpyDeviceToHost, g.s_out);
-            if (e == hipSuccess) e = hipEventRecord(ev_of(c, 3), g.s_out);
-        } else if (e == hipSuccess) {
-            e = hipEventRecord(ev_of(c, 3), h->stream);
+        // ---- the multiply; a one-block call (a signal shorter than a block with a one-partition IR) is a plain step
+        if (tiled) rc = tiled_mac(h, call);
+        else { rc = launch_step(h, a); if (rc == IRB_OK) h->t += 1; }
+        if (rc != IRB_OK) break;
+        if (device_times) (void) hipEventRecord(g.ev[1], h->stream);
+        // ---- out: inverse FFTs + overlap-add chunk by chunk, an event behind each
+        for (int k = 0; k < nio && rc == IRB_OK; k++) {
+            const int first = k * io, cnt = std::min(io, T - first);
+            if (tiled) rc = tiled_ifft(h, call, first, cnt);
+            if (rc == IRB_OK && hipEventRecord(g.ev[3 + k], h->stream) != hipSuccess) rc = fail(IRB_ERR_HIP, "hipEventRecord failed");
         }
-        if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "D2H: %s", hipGetErrorString(e)); break; }
-        enq = c + 1;
-        if (use_helper) g.unpacker.enqueued.store(enq, std::memory_order_release);
+        if (device_times) (void) hipEventRecord(g.ev[2], h->stream);
+        if (tiled && rc == IRB_OK) tiled_end(h, call);
+        if (rc != IRB_OK) break;
+        // ---- unpack: chunk k of this piece -> out, even k here, odd k on the unpacking thread
+        auto unpack = [&](int k, int who) -> int {
+            const double t0 = now_ms();
+            hipError_t e = hipEventSynchronize(g.ev[3 + k]);
+            if (e != hipSuccess) return fail(IRB_ERR_HIP, "waiting for an output chunk: %s", hipGetErrorString(e));
+            const double t1 = now_ms();
+            const int first = k * io, cnt = std::min(io, T - first);
+            const long s0 = (p0 + first) * B, n = (long) cnt * B;
+            const long take = std::max<long>(0, std::min<long>(n, lim - s0));
+            for (int ch = 0; ch < audio_ch; ch++)
+                if (take > 0) std::memcpy(out[ch] + s0, host_out + (size_t) ch * stride + (size_t) first * B, sizeof(float) * (size_t) take);
+            wait_ms[who] += t1 - t0;
+            unpack_ms[who] += now_ms() - t1;
+            return IRB_OK;
+        };
+        const bool helper = want_helper && nio >= 2;
+        if (helper) {
+            const int dev = device, n_odd = nio / 2;
+            g.unpacker.begin(n_odd, [&, dev](int i) { (void) hipSetDevice(dev); return unpack(2 * i + 1, 1); });
+            g.unpacker.enqueued.store(n_odd, std::memory_order_release);               // everything is enqueued already
+        }
+        for (int k = 0; k < nio && rc == IRB_OK; k += helper ? 2 : 1) rc = unpack(k, 0);
+        if (helper) {
+            const double t0 = now_ms();
+            const int rcu = g.unpacker.finish();
+            prof.stall_ms += now_ms() - t0;
+            if (rc == IRB_OK && rcu != IRB_OK) rc = fail(rcu, "one-shot pipeline: waiting for an output chunk failed on the unpacking thread");
+            prof.helper_thread = 1;
+        }
+        if (rc == IRB_OK && device_times) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;     // forward FFTs (incl. waiting for the host's packing) + multiply
+            if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;     // inverse FFTs + overlap-add
+        }
     }
-    if (use_helper) {
-        g.unpacker.limit.store(enq, std::memory_order_release);                      // (a failed call: what was enqueued is still drained)
-        const double t0 = now_ms();
-        const int rcu = g.unpacker.finish();
-        prof.stall_ms += now_ms() - t0;
-        if (rc == IRB_OK && rcu != IRB_OK) rc = fail(rcu, "one-shot pipeline: waiting for a chunk's device-to-host copy failed");
-    } else {
-        for (int c = std::max(0, enq - D); c < enq && rc == IRB_OK; c++) rc = unpack(c);
-    }
-    if (rc != IRB_OK) {                               // nothing of a failed call may still be writing the staging
-        (void) irb_sync(h);
-        (void) hipStreamSynchronize(g.s_in);
-        (void) hipStreamSynchronize(g.s_out);
-        return rc;
-    }
+    if (rc != IRB_OK) { (void) irb_sync(h); return rc; }          // nothing of a failed call may still be writing the staging
     prof.total_ms = now_ms() - t_begin;
-    prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms; prof.wait_ms = wait_ms;
-    prof.h2d_ms = device_times && mode == 0 ? h2d_ms : -1.0; prof.kernels_ms = device_times ? kern_ms : -1.0; prof.d2h_ms = device_times && mode == 0 ? d2h_ms : -1.0;
-    prof.chunks = nc; prof.blocks_per_chunk = chunk_pref; prof.last_chunk_blocks = Tneed; prof.steps = (int) steps;
-    prof.slots = D; prof.zero_copy = mode == 1; prof.helper_thread = use_helper;
-    prof.mac_on_matrix_cores = use_mfma(h, chunk_blocks(0)) ? 1 : 0;
+    prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1];
+    prof.wait_ms = wait_ms[0]; prof.wait_helper_ms = wait_ms[1];
+    prof.fft_in_and_mac_ms = device_times ? dev_ms[0] : -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;
+    prof.chunks = nio_total; prof.blocks_per_chunk = io; prof.pieces = pieces; prof.steps = (int) steps;
+    prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
+    {
+        const MfmaPlan pl = mfma_plan(h, Tneed);
+        prof.mac_launches = prof.mac_on_matrix_cores ? (pl.tilesB > 0 ? 2 : 1) : 1;
+    }
     g.prof = prof; g.have_prof = true;
     return rc;
 }

@@ -65,6 +65,17 @@ struct StepArgs {
     unsigned     *done;         // host-mapped word that receives done_seq after the last output store (nullptr: none)
     unsigned      done_seq;
     int           debug_drop;   // test hook (IRB_DEBUG_DROP_GRANULES): the last workgroup of the grid withholds its granules in this launch
+    // matrix-core path of long calls (fdl_mfma.hpp): the FDL and the IR spectra once more, time / tap contiguous per bin
+    float2       *Xt;           // [S][M][xt_len]: element xt_hist + t = block t of the call, [0, xt_hist) = the blocks before it
+    const float2 *Ht;           // [n_sets][M][ht_len]: element 16 + m = tap m (zeros in front and behind)
+    int           xt_len, xt_hist, ht_len;
+    int           tile_first, tile_count;   // the 256-block tiles this launch multiplies (a call may take two launches) ...
+    int           t_base, part_T;           // ... and where its partial spectra go: part[s][t - t_base][nq][M], part_T blocks per stream
+    // batched FFT kernels: the blocks [t_first, t_first + t_count) of the call (irb_convolve_periodic moves a call's blocks in and out in chunks)
+    int           t_first, t_count;
+    // k_ifft_ola_run: blocks from t_split on have their partial spectra in part2[s][t - t_split][nq2][M] (t_split = T: all in `part`)
+    const float2 *part2;
+    int           t_split, nq2;
 };
 
 #ifdef IRB_STAMPS
@@ -1055,7 +1066,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
 // is independent, and TT consecutive outputs share their H loads: a lane keeps a sliding window of
 // 2*TT-1 X rows and TT accumulators in registers (per outer step: TT new X rows + TT H rows feed
 // TT*TT complex multiply-adds per bin).  HBM/L2 traffic per output drops by ~TT versus streaming.
-//   k_push_fft_batch   grid = S*T (block index fastest)
+//   k_push_fft_batch   grid = S*t_count (block index fastest): blocks [t_first, t_first + t_count) of the call
 //   k_cmac_tiled       grid = S*ceil(T/TT)*splits: stripes own contiguous partition sub-ranges and
 //                      write their partial spectra straight from registers: part[s][j][q][M]
 //   k_ifft_ola_batch   grid = S*T: sums the nq partials of block j and of block j-1 (for its tail)
@@ -1068,8 +1079,8 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     __shared__ float2 l_buf[NF][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int item = blockIdx.x * NF + wave;
-    const bool live = item < S * a.T;
-    const int j = item % a.T, s = item / a.T;
+    const bool live = item < S * a.t_count;            // this launch: blocks [t_first, t_first + t_count) of the call
+    const int j = a.t_first + item % a.t_count, s = item / a.t_count;
     TwiddleStage<N, kWave * NF> tws;
     tws.load(a.tw);
     if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
@@ -1077,8 +1088,7 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     __syncthreads();
     if (!live) return;
     wave_fft<M, false>(l_buf[wave], l_tw, lane);
-    int slot = a.head + j;
-    if (slot >= a.R) slot -= a.R;
+    const int slot = (a.head + j) % a.R;
     float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
     wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
 }

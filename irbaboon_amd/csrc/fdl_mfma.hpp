@@ -1,4 +1,4 @@
-// fdl_mfma.hpp -- the time-tiled multiply-accumulate of long calls on the matrix cores (round 3).  Included by fdl_kernels.hpp.
+// fdl_mfma.hpp -- the time-tiled multiply-accumulate of long calls on the matrix cores.  Included by fdl_kernels.hpp.
 //
 // Along the time axis a bin of the frequency-domain delay line is a 1-D convolution,
 //     Y[t] = sum_{m < np} H[m] * X[t - m]                     (fp/convolution.cpp:185-205, one complex bin, all blocks of a call)
@@ -7,31 +7,38 @@
 //                                              Xc[c][k]  = X[16 c + k]       (the FDL's time axis folded into rows of 16).
 // Every M_j is dense (one triangle comes from chunk j of the IR spectra, the other from chunk j - 1), so the products carry no
 // structural zeros apart from the padding of np to whole chunks.  This is genuinely GEMM-shaped fp32 work -- per bin a
-// [T/16 x 16 J] x [16 J x 16] product -- and the exact-fp32 matrix instructions have the vector ALU's peak (157.3 TFLOP/s) but,
-// measured (tools/mfma_peak.hip, profiles/r03_mfma_peak.txt), sustain 0.89-0.97 of it from ONE wave per SIMD at 2.1-2.4 GHz, where
-// the packed-FMA kernel (fdl_tiled_pk.hpp) is issue-bound at 0.43 and pulls the clock to 1.7 GHz.
+// [T/16 x 16 J] x [16 J x 16] product -- on v_mfma_f32_16x16x4_f32 (exact fp32, the vector ALU's 157.3 TFLOP/s peak; measured with
+// tools/mfma_peak.hip: 0.89-0.97 of it from one wave per SIMD).
 //
-// A complex product is four real ones: Or = sum Xr Hr - sum Xi Hi (two accumulators, subtracted once: no sign flip in the loop),
-// Oi += Xi Hr + Xr Hi (the packed bin 0 -- DC and Nyquist, two real products -- takes the first of each only).  Workgroup = 16
-// neighbouring bins (one 128-byte line of every FDL / H / partial row) x one tile of 16 segments (256 output blocks) x one range
-// of j; 16 waves, one bin each (12 accumulator registers), four per SIMD: ONE wave cannot keep the matrix pipe full (its operand
-// reads and address updates sit between its own MFMAs: 39-49 cycles per 32-cycle MFMA measured, tools/mfma_stamps.hip), and two
-// waves that meet at a barrier every stage still left it idle a quarter of the time.
-// The range of j is walked in stages of kMfmaJC chunks: the H taps and X rows a stage needs go global -> registers -> LDS
-// (rows of 128 B: every line is used whole; buffer loads with the row step in an SGPR: no vector instruction per load) into one
-// half of the LDS while the other half is multiplied -- one barrier per stage of 9 chunks; 141 KiB of LDS for both --, X folded
-// as [k][row]: the 16 lanes of an operand read that share a k read 16 consecutive rows = 128 contiguous bytes (hipcc pairs the
-// reads into ds_read2_b64, which is banked per 16 lanes and 32 banks: with k % 2 innermost SQ_LDS_BANK_CONFLICT was 29 % of the
-// LDS cycles, now 2 % -- the kernel's time did not move: LDS is not what it waits for).  Per chunk a wave reads 8 operands of 8 bytes from LDS -- half a chunk ahead, in registers: a wave that waits for a
-// ds_read lets the matrix pipe run dry -- and issues 16 v_mfma_f32_16x16x4_f32 (512 cycles of matrix pipe).  The 256 x 16 results leave through LDS as whole 128-byte
-// rows of part[s][t][split][M] (summed over splits by k_ifft_ola_run, like those of k_cmac_tiled_pk).
+// Round 4: NO LDS staging and NO barrier in the loop.  Round 3's kernel brought the FDL rows [slot][bin] and the IR rows
+// [partition][bin] through a double-buffered LDS image, one barrier per stage of 9 chunks: 0.50 of the peak at configs[1], the
+// rest went to the first stage's burst, ~700 cycles per barrier round, a window re-loaded per stage and LDS operand reads
+// between the MFMAs.  Here the two operands are kept a SECOND time in the layout the instruction wants, written once by the
+// kernels that produce them:
+//     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin (k_push_fft_batch_t; the blocks before the call's
+//                                    first one sit in [0, xt_hist): k_xt_history rebuilds them from the ring when there are any)
+//     Ht[set][bin][16 + m]           the IR spectra with the tap index contiguous per bin, 16 zero taps in front, zeros behind
+//                                    (k_rows_to_columns at irb_fdl_set_ir*)
+// A wave owns ONE bin of one tile of 256 output blocks and one range of chunks, and nothing it reads is shared with another
+// wave through LDS: per chunk it issues 16 MFMAs and
+//   * 4 buffer loads of 8 B per lane for the H operand: lane (i, kq), k group g reads tap 16 j + i - 4 g - kq -- 31 consecutive taps
+//     of its bin, 2-3 cache lines, the same for every tile (L2 hits); negative and too large taps are the layout's zeros;
+//   * 4 buffer loads for the ONE new row of 16 blocks the X operand needs: operand lane (n, kq) of chunk j + 1 holds
+//     Xc[s0 + n - j - 1][4 g + kq], which is what lane (n - 1, kq) held for chunk j -- a DPP row shift (v_mov_b32 row_shr:1) moves the
+//     window along, and the lanes n = 0, which have no left neighbour, keep the freshly loaded value (bound_ctrl off).
+// Loads are issued one chunk of MFMAs ahead of their use into the register set the previous chunk has just released (two sets swap
+// roles, the loop is unrolled by two: no copies); the row step sits in an SGPR and the k group in the instruction's immediate
+// offset, so a chunk costs 8 VMEM + 8 DPP + a handful of scalar instructions next to its 16 MFMAs, in ~50 VGPRs.  The only LDS use
+// and the only barrier are at the end: the 256 x 16 results of the sixteen waves (bins) of a workgroup are transposed so that each
+// partial-spectrum row leaves as one whole 128-byte line (part[s][t][split][M], summed over splits by k_ifft_ola_run).
 //
 // Not bit-identical to the vector kernels (another summation order); parity with the oracle at the same tolerance (tests).
-// The index arithmetic (tiles, splits, stage windows, LDS images, operand positions) is restated in tests/kernel_model.py
-// (mfma_time_axis) and checked against the direct sum on a machine without a GPU.
-// Non-finite input: as with the zero rows that pad H to whole ring periods in fdl_tiled_pk.hpp, 0 * X products exist for X blocks
-// next to the ones an output really depends on (here: up to 255 blocks later / 31 blocks earlier), so an Inf or NaN sample
-// can spread further along the time axis than in the reference; finite input is unaffected.
+// The index arithmetic (tiles, splits, operand positions, the shifting window, the transposed layouts) is restated in
+// tests/kernel_model.py (mfma_time_axis) and checked against the direct sum on a machine without a GPU.
+// Non-finite input: 0 * X products exist for X blocks next to the ones an output really depends on (zero taps in front of
+// and behind the IR, up to 255 blocks later / 31 blocks earlier), so an Inf or NaN sample can spread further along the time
+// axis than in the reference; finite input is unaffected.  Xt is zeroed at create and only ever holds spectra, so the blocks
+// a tile reads beyond the end of a call are finite.
 #pragma once
 
 namespace irb {
@@ -42,45 +49,136 @@ constexpr int kMfmaSeg = 16;                           // segment length = MFMA 
 constexpr int kMfmaTile = kMfmaSeg * kMfmaSeg;         // output blocks per workgroup tile
 constexpr int kMfmaBins = 16;                          // bins per workgroup = waves per workgroup
 constexpr int kMfmaThreads = kMfmaBins * kWave;        // 1024
-constexpr int kMfmaSR = kMfmaThreads / kMfmaBins;      // FDL rows a staging pass covers: 64 = four X rows of 16 blocks
-#ifndef IRB_MFMA_JC
-#define IRB_MFMA_JC 9
-#endif
-constexpr int kMfmaJC = IRB_MFMA_JC;                   // Toeplitz chunks per LDS stage (tools/mfma_stamps.hip builds variants)
-constexpr int kMfmaNC = kMfmaJC + kMfmaSeg - 1;        // X rows (of 16 blocks) a stage needs
-constexpr int kMfmaNH = kMfmaJC + 2;                   // H chunks a stage needs (one before, up to one after)
-constexpr int kMfmaXI = (kMfmaNC + 3) / 4, kMfmaHI = (kMfmaNH + 3) / 4;     // staging passes
-// per-bin LDS strides in float2, 1 (mod 16): the 16 bins a 16-lane group of ds_write_b64 stages fall into the 32 banks once
-constexpr int kMfmaXS = kMfmaSeg * kMfmaNC + 1;
-constexpr int kMfmaHS = kMfmaSeg * kMfmaNH + 1;
-constexpr int kMfmaStage = kMfmaBins * (kMfmaXS + kMfmaHS);    // float2 per stage image: X as [bin][k][X row], then H as [bin][m]
 constexpr int kMfmaOS = kMfmaBins + 1;                 // row stride of the output tile in LDS
-constexpr size_t kMfmaLds = 2 * kMfmaStage * sizeof(float2);   // dynamic LDS of a launch (two stage images)
-static_assert(kMfmaSR == 4 * kMfmaSeg, "a staging pass is four X rows / four H chunks");
-static_assert(kMfmaTile * kMfmaOS <= kMfmaStage, "the output tile reuses a stage image");
 
 // chunks of the Toeplitz sum for np partitions: j = 0 .. J-1 covers every m = 16 j + i - k in [0, np)
 __host__ __device__ constexpr int mfma_chunks(int np) { return np > 0 ? (np + kMfmaSeg - 2) / kMfmaSeg + 1 : 0; }
+// blocks of history in front of a call's first block in Xt: chunk J - 1 of tile 0 reads back to -16 (J - 1), the loads that run
+// ahead of the last chunk to -16 (J + 1) -- everything the kernel addresses exists, nothing depends on buffer range checks
+__host__ __device__ constexpr int mfma_hist(int P) { return kMfmaSeg * (mfma_chunks(P) + 2); }
+// taps per bin row of Ht: 16 zeros, the taps, zeros up to the last index the run-ahead loads read (16 + 16 (J + 1) + 15)
+__host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chunks(P) + 3); }
 
-// One stage of one wave: jc chunks of its bin out of a stage image.  Unit = half a chunk: X operand lane (n, kq) <- Xc[s0 + n - j][4 g + kq]
-// at xb[4 g NC - j], H operand lane (i, kq) <- H[16 j + i - 4 g - kq] at hb[16 j - 4 g], g = 0, 1 / 2, 3; the operands of the
-// next unit are read while this one is multiplied.  PACKED (bin 0: DC and Nyquist, two real products) is a template parameter, the
-// last chunk is peeled: no branch between the MFMAs of a stage but the loop's own (with a wave-uniform `if (packed)` around every
-// unit the kernel executed 0.7 branches and 3.4 scalar instructions per MFMA, and one wave needed ~45 cycles per 32-cycle MFMA).
-template <bool PACKED>
-__device__ __forceinline__ void mfma_stage(const float2 *xb, const float2 *hb, int jc, v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i)
+// ---------------------------------------------------------------------------------------------
+// k_rows_to_columns: rows [r0, r0 + nrows) of a [row][M] spectrum array (ring addressed: physical row (first + r) mod R) become
+// columns [c0 + r] of a [M][ldc] array; rows at or beyond `valid` are written as zeros.  Used for Ht (IR spectra -> tap-contiguous,
+// at set-up) and for Xt's history (the FDL ring's last blocks -> time-contiguous, before a matrix-core call that continues a stream).
+// A workgroup transposes 16 rows x 64 bins through LDS: 512-byte pieces in, whole 128-byte lines out.
+// grid = (ceil(nrows / 16), M / 64 or 1, sets), block = 256.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restrict__ src, long src_set_stride, int first, int R, int valid,
+                                                          float2 *__restrict__ dst, long dst_set_stride, int ldc, int c0, int nrows)
 {
-    auto read_ops = [&](float2 (&x)[2], float2 (&h)[2], int j, int half) {
-#pragma unroll
-        for (int gg = 0; gg < 2; gg++) {
-            const int g = 2 * half + gg;
-            x[gg] = xb[4 * g * kMfmaNC - j];
-            h[gg] = hb[kMfmaSeg * j - 4 * g];
+    constexpr int BW = M < 64 ? M : 64;                // bins per workgroup
+    __shared__ float2 l_t[16][BW + 1];
+    const int r0 = blockIdx.x * 16, b0 = blockIdx.y * BW, set = blockIdx.z;
+    const float2 *s = src + (size_t) set * src_set_stride;
+    float2 *d = dst + (size_t) set * dst_set_stride;
+    for (int e = threadIdx.x; e < 16 * BW; e += 256) {
+        const int r = e / BW, b = e % BW;
+        float2 v = make_float2(0.f, 0.f);
+        if (r0 + r < nrows && r0 + r < valid) {
+            int pr = first + r0 + r;
+            if (R > 0) { pr %= R; if (pr < 0) pr += R; }
+            v = s[(size_t) pr * M + b0 + b];
         }
-    };
-    auto multiply = [&](const float2 (&x)[2], const float2 (&h)[2]) {
+        l_t[r][b] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * BW; e += 256) {
+        const int b = e / 16, r = e % 16;
+        if (r0 + r < nrows) d[(size_t) (b0 + b) * ldc + c0 + r0 + r] = l_t[r][b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_push_fft_batch_t: the forward FFTs of blocks [t_first, t_first + t_count) of a call (k_push_fft_batch's work) for engines
+// whose long calls multiply on the matrix cores: every spectrum is written twice -- into the FDL ring (what every other kernel
+// reads and what the next call's history is rebuilt from) and, through LDS, into Xt with time contiguous per bin.
+// A workgroup = NBW consecutive blocks of one stream, one wave each; Xt leaves in pieces of NBW * 8 bytes (whole 128-byte lines
+// for N <= 512).  grid = S * ceil(t_count / NBW); t_first is a multiple of NBW.
+// ---------------------------------------------------------------------------------------------
+template <int N> struct PushTGeom { static constexpr int NBW = N <= 512 ? 16 : N == 1024 ? 8 : N == 2048 ? 4 : 2; };
+
+template <int N>
+__global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(StepArgs a, int S)
+{
+    constexpr int M = N / 2, NBW = PushTGeom<N>::NBW;
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[NBW][M + 1];               // (+1: the transposed read below walks the block index at a fixed bin)
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int groups = (a.t_count + NBW - 1) / NBW;
+    const int s = blockIdx.x / groups, j0 = a.t_first + (blockIdx.x % groups) * NBW;
+    const int j = j0 + wave;
+    const bool live = j < a.t_first + a.t_count;
+    TwiddleStage<N, kWave * NBW> tws;
+    tws.load(a.tw);
+    if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
+    tws.store(l_tw);
+    __syncthreads();
+    if (live) {
+        wave_fft<M, false>(l_buf[wave], l_tw, lane);
+        int slot = (a.head + j) % a.R;
+        float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
+        // the split reads bins b and M - b of the transform and writes the same two positions: in place, after all reads of the wave
+        float2 *lb = l_buf[wave];
+        wave_split_forward<M>(lb, l_tw, lane, [&](int b, float2 v) { dst[b] = v; lb[b] = v; });
+    }
+    __syncthreads();
+    // Xt[s][bin][xt_hist + j0 .. + NBW): thread -> (bin, piece of 4 blocks)
+    constexpr int Q = NBW >= 4 ? NBW / 4 : 1, E = NBW >= 4 ? 4 : NBW;
+    float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist + j0;
+    for (int e = threadIdx.x; e < M * Q; e += kWave * NBW) {
+        const int bin = e / Q, q = e % Q;
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int i = 0; i < E; i++)
+            if (j0 + E * q + i < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + E * q + i] = l_buf[E * q + i][bin];
+    }
+}
+
+// 8-byte buffer load: per-lane byte offset in a VGPR, row step in an SGPR, k group in the immediate; out of range reads 0
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <int IMM>
+__device__ __forceinline__ float2 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff + IMM, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
+// one component of the X operand moves one segment along: lane (n, kq) takes lane (n - 1, kq)'s value, lanes n = 0 keep `fresh`
+__device__ __forceinline__ float shift_in(float fresh, float window)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fresh), __float_as_int(window), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+
+// The chunks [jb, je) of one wave: its bin of one tile.  PACKED = bin 0 (DC and Nyquist: two real products).
+//   x operand of chunk j, k group g, lane (n, kq):  Xt[xt_hist + 256 tile + 16 (n - j) + 4 g + kq]
+//   h operand                       lane (i, kq):  Ht[16 + 16 j + i - 4 g - kq]
+template <bool PACKED>
+__device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rh, int lane, int x_elem0, int jb, int je,
+                                               v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i)
+{
+    const int n = lane % kMfmaSeg, kq = lane / kMfmaSeg;
+    const unsigned vx_win = (unsigned) (kMfmaSeg * n + kq) * 8u, vx_new = (unsigned) kq * 8u, vh = (unsigned) (n - kq + 3) * 8u;
+    // scalar byte offsets: the window of chunk jb, the new row of chunk j (element x_elem0 - 16 j), the taps of chunk j
+    auto sx = [&](int j) { return (unsigned) (x_elem0 - kMfmaSeg * j) * 8u; };
+    auto sh = [&](int j) { return (unsigned) (kMfmaSeg * j) * 8u; };
+    // Two register sets that swap roles every chunk (the loop is unrolled by two, so nothing is ever copied): while set A is
+    // multiplied, set B holds the next chunk's taps and -- in its lanes n = 0 -- the next chunk's new row of blocks; the DPP shift
+    // then completes B's window from A's in place, and A, now free, receives the loads of the chunk after that.  A load is issued
+    // one chunk of MFMAs (512 cycles alone, ~2000 with the SIMD's other waves) before its first use.
+    float2 xa[4], ha[4], xb[4], hb[4];
+    auto load_h = [&](float2 (&h)[4], int j) {
+        h[0] = buf_ld8<(13 - 0) * 8>(rh, vh, sh(j)); h[1] = buf_ld8<(13 - 4) * 8>(rh, vh, sh(j));
+        h[2] = buf_ld8<(13 - 8) * 8>(rh, vh, sh(j)); h[3] = buf_ld8<(13 - 12) * 8>(rh, vh, sh(j));
+    };
+    auto load_x = [&](float2 (&x)[4], unsigned v, int j) {
+        x[0] = buf_ld8<0>(rx, v, sx(j)); x[1] = buf_ld8<32>(rx, v, sx(j)); x[2] = buf_ld8<64>(rx, v, sx(j)); x[3] = buf_ld8<96>(rx, v, sx(j));
+    };
+    auto multiply = [&](const float2 (&x)[4], const float2 (&h)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
             if constexpr (PACKED) {
                 acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].x, h[g].x, acc_r, 0, 0, 0);
                 acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].y, h[g].y, acc_i, 0, 0, 0);
@@ -92,42 +190,47 @@ __device__ __forceinline__ void mfma_stage(const float2 *xb, const float2 *hb, i
             }
         }
     };
-    float2 x0[2], h0[2], x1[2], h1[2];
-    read_ops(x0, h0, 0, 0);
+    // chunk j is multiplied out of (xc, hc); (xn, hn) -- loaded for chunk j + 1 -- becomes its window; then (xc, hc) is reloaded for chunk j + 2
+    auto step = [&](int j, float2 (&xc)[4], float2 (&hc)[4], float2 (&xn)[4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(xc, hc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; g++) xn[g] = make_float2(shift_in(xn[g].x, xc[g].x), shift_in(xn[g].y, xc[g].y));
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(xc, vx_new, j + 2);                     // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
+        load_h(hc, j + 2);
+    };
+    load_x(xa, vx_win, jb);
+    load_h(ha, jb);
+    load_x(xb, vx_new, jb + 1);
+    load_h(hb, jb + 1);
+    int j = jb;
 #pragma unroll 1
-    for (int j = 0; j < jc - 1; j++) {
-        read_ops(x1, h1, j, 1);
-        __builtin_amdgcn_sched_barrier(0);                         // reads first: left alone, the compiler sinks each one to its use
-        multiply(x0, h0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_ops(x0, h0, j + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(x1, h1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (; j + 1 < je; j += 2) {
+        step(j, xa, ha, xb);
+        step(j + 1, xb, hb, xa);
     }
-    read_ops(x1, h1, jc - 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(x0, h0);
-    multiply(x1, h1);
+    if (j < je) { __builtin_amdgcn_sched_barrier(0); multiply(xa, ha); }
 }
 
-// grid = S * ceil(T / 256) * splits * (M / 16); block = 1024; dynamic LDS = kMfmaLds.  part[s][t][split][M] like k_cmac_tiled_pk
-// (a.nq = a.splits).
+// grid = S * tile_count * splits * (M / 16); block = 1024.  Partial spectra: part[s][t - t_base][split][M], part_T blocks per
+// stream (a call may be multiplied in two launches -- whole rounds of workgroups, then the remaining tiles with more partition
+// splits -- each with its own partial-spectrum region; see launch_tiled).
 template <int N>
-__global__ __launch_bounds__(kMfmaThreads, 1) void k_cmac_mfma(StepArgs a)
+__global__ __launch_bounds__(kMfmaThreads, 2) void k_cmac_mfma(StepArgs a)
 {
     constexpr int M = N / 2;
     static_assert(M % kMfmaBins == 0, "bins per workgroup");
     constexpr int GROUPS = M / kMfmaBins;
-    extern __shared__ float2 l_stage[];                            // [2][kMfmaStage]
-    const int ntiles = (a.T + kMfmaTile - 1) / kMfmaTile;
-    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // the bin groups and splits of one tile share an XCD's L2 (the same FDL rows)
-    const int bg = wg % GROUPS, split = (wg / GROUPS) % a.splits, tile = (wg / (GROUPS * a.splits)) % ntiles, s = wg / (GROUPS * a.splits * ntiles);
+    __shared__ float2 l_o[kMfmaTile * kMfmaOS];
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // the bin groups and splits of one tile share an XCD's L2 (the same FDL lines)
+    const int bg = wg % GROUPS, split = (wg / GROUPS) % a.splits, tile = a.tile_first + (wg / (GROUPS * a.splits)) % a.tile_count,
+              s = wg / (GROUPS * a.splits * a.tile_count);
     const int2 si = a.stream_info[s];
     const int set = si.x, np = si.y;
     const int J = mfma_chunks(np);
     const int jb = (int) ((long) J * split / a.splits), je = (int) ((long) J * (split + 1) / a.splits);
-    const int s0 = tile * kMfmaSeg;                                // first segment of the tile
     const int b0 = bg * kMfmaBins;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
     IRB_STAMP(a, 0);
@@ -136,130 +239,30 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_cmac_mfma(StepArgs a)
         a.stamps[(size_t) blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         a.stamps[(size_t) blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
     }
-    unsigned long long t_mult = 0, t_mark = 0;
 #endif
-
-    // ---- staging: thread (sbin, srow) brings FDL rows srow + 64 it of its bin = block k = sk of X rows 4 it + sc, and taps
-    // srow + 64 it of H.  fetch(): buffer loads into registers (one VGPR offset per thread and stage, the row step in an SGPR: no
-    // vector instruction per load on the common path -- every instruction here is issued between this SIMD's MFMAs); rows outside
-    // (-np, T) x [0, np) read as zero: their offset is pushed out of the descriptor's range.  put(): registers -> image p.
-    constexpr unsigned ROWB = M * sizeof(float2), STEP = kMfmaSR * ROWB, OOR = 0x80000000u;
-    const int sbin = tid % kMfmaBins, srow = tid / kMfmaBins, sk = srow % kMfmaSeg, sc = srow / kMfmaSeg;
-    const unsigned colb = (unsigned) (b0 + sbin) * (unsigned) sizeof(float2);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.X + (size_t) s * a.R * M), 0, (int) ((unsigned) a.R * ROWB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.H + (size_t) set * a.P * M), 0, (int) ((unsigned) a.P * ROWB), 0x00020000);
-    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-    auto as_f2 = [](v2u_t v) { return make_float2(__uint_as_float(v.x), __uint_as_float(v.y)); };
-    float2 xr[kMfmaXI], hr[kMfmaHI];
-    auto fetch = [&](int ja, int jc) {
-        const int nx = jc + kMfmaSeg - 1, nh = jc + 2;             // X rows / H chunks this stage uses
-        const int tau_lo = kMfmaSeg * (s0 - ja - jc + 1), m_lo = kMfmaSeg * ja - kMfmaSeg;      // uniform
-        int first = (a.head + tau_lo) % a.R;                       // ring slot of the stage's first row (uniform)
-        if (first < 0) first += a.R;
-        if (tau_lo > -np && tau_lo + kMfmaSeg * nx <= a.T && nx == kMfmaNC && first + kMfmaSR * kMfmaXI <= a.R) {
-            // every row exists and the ring does not wrap inside the passes (the last pass reads up to three rows the stage never uses)
-            const unsigned vo = (unsigned) (first + srow) * ROWB + colb;
-#pragma unroll
-            for (int it = 0; it < kMfmaXI; it++) xr[it] = as_f2(__builtin_amdgcn_raw_buffer_load_b64(rx, vo, it * STEP, 0));
-        } else {
-#pragma unroll
-            for (int it = 0; it < kMfmaXI; it++) {
-                const int tau = tau_lo + srow + kMfmaSR * it;      // block time relative to the call's first block
-                int sl = a.head + tau;                             // in (-R, 2 R) whenever the row exists
-                if (sl < 0) sl += a.R;
-                if (sl >= a.R) sl -= a.R;
-                const bool ok = 4 * it + sc < nx && tau > -np && tau < a.T;
-                xr[it] = as_f2(__builtin_amdgcn_raw_buffer_load_b64(rx, ok ? (unsigned) sl * ROWB + colb : OOR, 0, 0));
-            }
-        }
-        if (m_lo >= 0 && m_lo + kMfmaSR * kMfmaHI <= np && nh == kMfmaNH) {
-            const unsigned vo = (unsigned) (m_lo + srow) * ROWB + colb;
-#pragma unroll
-            for (int it = 0; it < kMfmaHI; it++) hr[it] = as_f2(__builtin_amdgcn_raw_buffer_load_b64(rh, vo, it * STEP, 0));
-        } else {
-#pragma unroll
-            for (int it = 0; it < kMfmaHI; it++) {
-                const int m = m_lo + srow + kMfmaSR * it;
-                const bool ok = 4 * it + sc < nh && m >= 0 && m < np;
-                hr[it] = as_f2(__builtin_amdgcn_raw_buffer_load_b64(rh, ok ? (unsigned) m * ROWB + colb : OOR, 0, 0));
-            }
-        }
-    };
-    auto put = [&](int p) {
-        float2 *sx = l_stage + p * kMfmaStage + sbin * kMfmaXS + (sk * kMfmaNC + sc);
-        float2 *sh = l_stage + p * kMfmaStage + kMfmaBins * kMfmaXS + sbin * kMfmaHS + srow;
-#pragma unroll
-        for (int it = 0; it < kMfmaXI; it++)
-            if (4 * it + 3 < kMfmaNC || 4 * it + sc < kMfmaNC) sx[4 * it] = xr[it];
-#pragma unroll
-        for (int it = 0; it < kMfmaHI; it++)
-            if (4 * it + 3 < kMfmaNH || 4 * it + sc < kMfmaNH) sh[kMfmaSR * it] = hr[it];
-    };
-
-    // ---- multiplying: wave w owns bin b0 + w
-    const int n = lane % kMfmaSeg, kq = lane / kMfmaSeg;           // MFMA operand position: free index = lane % 16, k = 4 g + lane / 16
+    const int bin = b0 + wave;                                     // wave-uniform: the descriptors below live in scalar registers
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.Xt + ((size_t) s * M + bin) * a.xt_len, 0, a.xt_len * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.Ht) + ((size_t) set * M + bin) * a.ht_len, 0, a.ht_len * 8, 0x00020000);
     v4f_t acc_r, acc_n, acc_i;                                     // O[n = 4 kq + v][i = lane % 16]: re = acc_r - acc_n (Xr Hr and Xi Hi apart), im
 #pragma unroll
     for (int v = 0; v < 4; v++) { acc_r[v] = 0.f; acc_n[v] = 0.f; acc_i[v] = 0.f; }
-    const bool packed = b0 + wave == 0;                            // wave-uniform: the bin that holds DC and Nyquist
-    auto multiply_stage = [&](int jc, int p) {
-        const float2 *xb = l_stage + p * kMfmaStage + wave * kMfmaXS + (kq * kMfmaNC + n + jc - 1);
-        const float2 *hb = l_stage + p * kMfmaStage + kMfmaBins * kMfmaXS + wave * kMfmaHS + (kMfmaSeg + n - kq);
-        if (packed) mfma_stage<true>(xb, hb, jc, acc_r, acc_n, acc_i);
-        else        mfma_stage<false>(xb, hb, jc, acc_r, acc_n, acc_i);
-    };
-
-    // Stage st is multiplied out of image st % 2.  Behind the barrier that ends stage st - 1 every wave first stores the rows of stage
-    // st + 1 (loaded a whole stage ago) into the image that barrier has just released and asks for the rows of stage st + 2, then
-    // multiplies: a few dozen instructions per wave, and those of the younger waves are issued under the older waves' MFMAs -- the
-    // matrix pipe stands still only from the last wave's last MFMA over the barrier to the first wave's first.  (With the store at the
-    // END of a stage, after the wave's MFMAs, every stage cost ~2700 cycles of idle pipe on top of its 12 300 of MFMAs.)
-    const int nst = (je - jb + kMfmaJC - 1) / kMfmaJC;
-    auto stage_begin = [&](int st) { return min(jb + kMfmaJC * st, je); };
-    if (nst > 0) { fetch(jb, stage_begin(1) - jb); put(0); }
-    if (nst > 1) fetch(stage_begin(1), stage_begin(2) - stage_begin(1));
-    __syncthreads();
-    IRB_STAMP(a, 1);
-#ifdef IRB_STAMPS
-    t_mark = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll 1
-    for (int st = 0; st < nst; st++) {
-        // (at raised priority: at equal priority the arbiter serves the oldest wave's MFMA stream first, the youngest waves took 16 000 cycles
-        // to get through these few dozen instructions and then multiplied alone at the end of the stage -- tools/mfma_stamps.hip ... waves)
-        __builtin_amdgcn_s_setprio(3);
-        if (st + 1 < nst) put((st & 1) ^ 1);
-        if (st + 2 < nst) fetch(stage_begin(st + 2), stage_begin(st + 3) - stage_begin(st + 2));
-        __builtin_amdgcn_s_setprio(0);
-#ifdef IRB_STAMPS
-        const unsigned long long t_in = __builtin_amdgcn_s_memtime();
-#endif
-        multiply_stage(stage_begin(st + 1) - stage_begin(st), st & 1);
-#ifdef IRB_STAMPS
-        const unsigned long long t_out = __builtin_amdgcn_s_memtime();
-        t_mult += t_out - t_in;
-        if (blockIdx.x == gridDim.x / 2 && lane == 0 && st < 4) {         // one workgroup's per-wave timeline, behind the per-workgroup records
-            unsigned long long *w = a.stamps + (size_t) gridDim.x * 16 + wave * 16 + st * 4;
-            w[0] = t_mark; w[1] = t_in; w[2] = t_out;
-            w[3] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_ID: SIMD in bits 5:4
-        }
-#endif
-        __syncthreads();                                           // image st % 2 has been multiplied by everyone; image (st + 1) % 2 is complete
+    const int x_elem0 = a.xt_hist + kMfmaTile * tile;              // Xt element of the tile's first block
+    if (jb < je) {
+        if (bin == 0) mfma_chunk_run<true>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i);
+        else          mfma_chunk_run<false>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i);
     }
     IRB_STAMP(a, 2);
-#ifdef IRB_STAMPS
-    if (threadIdx.x == 0) a.stamps[(size_t) blockIdx.x * 16 + 4] = t_mult;      // wave 0: cycles inside multiply_stage (the rest of the loop: staging stores, barriers)
-#endif
-    // ---- store: accumulator register v of lane (i, kq) is O[n = 4 kq + v][i], i.e. block 16 (s0 + n) + i of the call; through LDS,
-    // so that each output row leaves as one whole 128-byte line
-    float2 *l_o = l_stage;
+    // ---- store: accumulator register v of lane (i, kq) is O[n = 4 kq + v][i], i.e. block 256 tile + 16 n + i of the call; through
+    // LDS, so that each output row leaves as one whole 128-byte line
+    const int i = lane % kMfmaSeg, kq = lane / kMfmaSeg;
 #pragma unroll
-    for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + n) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], acc_i[v]);
+    for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + i) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], acc_i[v]);
     __syncthreads();
+    const int sbin = tid % kMfmaBins, srow = tid / kMfmaBins;
 #pragma unroll
-    for (int it = 0; it < kMfmaTile / kMfmaSR; it++) {
-        const int tl = srow + kMfmaSR * it, t = kMfmaTile * tile + tl;
-        if (t < a.T) a.part[(((size_t) s * a.T + t) * a.nq + split) * M + b0 + sbin] = l_o[tl * kMfmaOS + sbin];
+    for (int it = 0; it < kMfmaTile / (kMfmaThreads / kMfmaBins); it++) {
+        const int tl = srow + (kMfmaThreads / kMfmaBins) * it, t = kMfmaTile * tile + tl;
+        if (t < a.T) a.part[(((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin] = l_o[tl * kMfmaOS + sbin];
     }
     IRB_STAMP(a, 7);
 }

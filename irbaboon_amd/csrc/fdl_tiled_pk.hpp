@@ -200,10 +200,11 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
     __shared__ float2 l_tw[TwLds<N>::SIZE];
     __shared__ float2 l_buf[NB + 1][M];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int runs = (a.T + NB - 1) / NB;
-    const int s = blockIdx.x / runs, jb = (blockIdx.x % runs) * NB;
+    // this launch covers blocks [t_first, t_first + t_count) of the call (t_first a multiple of NB)
+    const int runs = (a.t_count + NB - 1) / NB;
+    const int s = blockIdx.x / runs, jb = a.t_first + (blockIdx.x % runs) * NB;
     const int j = jb - 1 + wave;                       // this wave's block
-    const bool live = j < a.T && (j >= 0);
+    const bool live = j < a.t_first + a.t_count && (j >= 0);
     const float scale = 1.0f / (float) N;
     float2 *buf = l_buf[wave];
     float *yw = reinterpret_cast<float *>(buf);
@@ -215,7 +216,10 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
 #pragma unroll
         for (int i = 0; i < VPL; i++) ov[i] = o[min(lane + i * kWave, a.B - 1)];
     }
-    if (live) wave_sum_rows<N>(a.part + ((size_t) s * a.T + j) * a.nq * M, a.nq, buf, lane);
+    if (live) {
+        if (j >= a.t_split) wave_sum_rows<N>(a.part2 + ((size_t) s * (a.T - a.t_split) + (j - a.t_split)) * a.nq2 * M, a.nq2, buf, lane);
+        else                wave_sum_rows<N>(a.part + ((size_t) s * a.t_split + j) * a.nq * M, a.nq, buf, lane);
+    }
     tws.store(l_tw);
     __syncthreads();
     if (live) {

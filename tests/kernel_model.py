@@ -212,8 +212,7 @@ def rows_split_layout(M1, M2, R):
 
 
 # ---- csrc/fdl_mfma.hpp: the time axis of one bin as Toeplitz-block products ---------------------------------------
-MFMA_SEG, MFMA_JC = 16, 9
-MFMA_NC, MFMA_NH = MFMA_JC + MFMA_SEG - 1, MFMA_JC + 2
+MFMA_SEG, MFMA_TILE = 16, 256
 
 
 def mfma_chunks(np_):
@@ -221,48 +220,108 @@ def mfma_chunks(np_):
     return (np_ + MFMA_SEG - 2) // MFMA_SEG + 1 if np_ > 0 else 0
 
 
-def mfma_time_axis(X, H, T, splits=1):
-    """k_cmac_mfma for ONE bin: X[tau] for tau in (-np, T) (dict-like: callable tau -> complex, zero outside), H[m], m < np.
-    Walks tiles of 256 output blocks, partition splits and stages of MFMA_JC chunks exactly as the kernel does -- stage windows
-    (tau_lo, m_lo), the LDS images' index formulas, the operand positions of lane (n, kq) at (chunk j, k group g), the output
-    register map -- and returns [splits][T] partial sums (float64: this checks indices, not rounding)."""
+def mfma_hist(P):
+    return MFMA_SEG * (mfma_chunks(P) + 2)
+
+
+def mfma_taps(P):
+    return MFMA_SEG * (mfma_chunks(P) + 3)
+
+
+def mfma_plan(T, units, P, wgs=256, min_chunks=6):
+    """fdl_engine.hip: mfma_plan -- (tilesA, splitsA, tilesB, splitsB): whole rounds of workgroups unsplit, then the remaining tiles
+    with their partitions split; units = streams x bin groups = workgroups per tile at one split"""
+    ntiles = (T + MFMA_TILE - 1) // MFMA_TILE
+    by_work = max(1, mfma_chunks(P) // min_chunks)
+    splits_for = lambda w: max(1, min(by_work, wgs // max(1, w)))
+    per_round = wgs // units
+    full = ntiles // per_round * per_round if per_round > 0 else ntiles
+    if full == 0 or full == ntiles:
+        return ntiles, (splits_for(ntiles * units) if ntiles * units < wgs else 1), 0, 1
+    return full, 1, ntiles - full, splits_for((ntiles - full) * units)
+
+
+def mfma_layouts(X, H, T, P):
+    """The operands as the kernels that produce them lay them out for ONE bin: Xt = [history | the call's blocks | zeros up to whole
+    tiles] (k_xt_history / irb_fdl_reset, k_push_fft_batch_t), Ht = [16 zeros | taps | zeros] (k_rows_to_columns).
+    X: callable tau -> complex for tau in [-hist, T); H: the np taps in use (np <= P)."""
+    hist, taps = mfma_hist(P), mfma_taps(P)
+    Tpad = (T + MFMA_TILE - 1) // MFMA_TILE * MFMA_TILE
+    xt = np.zeros(hist + Tpad, np.complex128)
+    for tau in range(-hist, T):
+        xt[hist + tau] = X(tau)
+    xt[hist + T:] = 12345.0 + 6789.0j                  # what an earlier, longer call left behind: finite, must not matter
+    ht = np.zeros(taps, np.complex128)
+    ht[16:16 + len(H)] = H
+    return xt, ht, hist
+
+
+def mfma_wave(xt, ht, hist, tile, jb, je):
+    """mfma_chunk_run for one wave (one bin of one tile, chunks [jb, je)): byte offsets of the buffer loads (per-lane voffset, scalar
+    offset, immediate), the two register sets that swap roles, the DPP row shift that moves the X window along, the MFMA's operand
+    and result maps.  Returns O[n][i] (16 x 16)."""
+    lanes = [(l % 16, l // 16) for l in range(64)]                 # (n or i, kq)
+    x_elem0 = hist + MFMA_TILE * tile
+    ld = lambda buf, byte: buf[byte // 8] if 0 <= byte // 8 < len(buf) else 0.0   # (nothing the kernel addresses is out of range: asserted below)
+    sx = lambda j: (x_elem0 - 16 * j) * 8
+    sh = lambda j: 16 * j * 8
+
+    def load_x(vx, j):
+        for g in range(4):
+            for n, kq in lanes:
+                assert 0 <= (vx(n, kq) + sx(j) + 32 * g) // 8 < len(xt)
+        return [[ld(xt, vx(n, kq) + sx(j) + 32 * g) for n, kq in lanes] for g in range(4)]
+
+    def load_h(j):
+        for g in range(4):
+            for i, kq in lanes:
+                assert 0 <= ((i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) // 8 < len(ht)
+        return [[ld(ht, (i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) for i, kq in lanes] for g in range(4)]
+
+    vx_win, vx_new = (lambda n, kq: (16 * n + kq) * 8), (lambda n, kq: kq * 8)
+    acc = np.zeros((16, 16), np.complex128)
+
+    def multiply(x, h):
+        for g in range(4):
+            for l, (n, kq) in enumerate(lanes):                     # A operand lane (row n, k = kq), B operand lane (k = kq, column i)
+                for l2, (i, kq2) in enumerate(lanes):
+                    if kq2 == kq:
+                        acc[n, i] += x[g][l] * h[g][l2]
+
+    def shift_in(fresh, window):                                   # v_mov_b32_dpp row_shr:1, bound_ctrl off: lanes n = 0 keep `fresh`
+        return [[fresh[g][l] if n == 0 else window[g][l - 1] for l, (n, kq) in enumerate(lanes)] for g in range(4)]
+
+    xa, ha = load_x(vx_win, jb), load_h(jb)
+    xb, hb = load_x(vx_new, jb + 1), load_h(jb + 1)
+    j = jb
+    while j + 1 < je:
+        multiply(xa, ha); xb = shift_in(xb, xa); xa, ha = load_x(vx_new, j + 2), load_h(j + 2)
+        multiply(xb, hb); xa = shift_in(xa, xb); xb, hb = load_x(vx_new, j + 3), load_h(j + 3)
+        j += 2
+    if j < je:
+        multiply(xa, ha)
+    return acc
+
+
+def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
+    """k_cmac_mfma + the two-launch plan + k_ifft_ola_run's sum over partial spectra, for ONE bin: returns Y[t], t < T (float64:
+    this checks indices, not rounding)."""
     np_ = len(H)
+    P = np_ if P is None else P
+    xt, ht, hist = mfma_layouts(X, H, T, P)
     J = mfma_chunks(np_)
-    out = np.zeros((splits, T), np.complex128)
-    x_at = lambda tau: X(tau) if -np_ < tau < T else 0.0
-    h_at = lambda m: H[m] if 0 <= m < np_ else 0.0
-    for tile in range((T + 255) // 256):
-        s0 = tile * MFMA_SEG
-        for split in range(splits):
-            jb, je = J * split // splits, J * (split + 1) // splits
-            acc = np.zeros((MFMA_SEG, MFMA_SEG), np.complex128)          # O[n][i]
-            for ja in range(jb, je, MFMA_JC):
-                jc = min(MFMA_JC, je - ja)
-                tau_lo, m_lo = MFMA_SEG * (s0 - ja - jc + 1), MFMA_SEG * ja - MFMA_SEG
-                # the stage images: X as [k][X row], H as [m - m_lo]; staging thread srow -> k = srow % 16, row 4 it + srow / 16
-                lx = np.zeros(MFMA_SEG * MFMA_NC, np.complex128)
-                lh = np.zeros(MFMA_SEG * MFMA_NH, np.complex128)
-                for srow in range(64):
-                    sk, sc = srow % MFMA_SEG, srow // MFMA_SEG
-                    for it in range((MFMA_NC + 3) // 4):
-                        c = 4 * it + sc
-                        if c < MFMA_NC:
-                            ok = c < jc + MFMA_SEG - 1
-                            lx[sk * MFMA_NC + sc + 4 * it] = x_at(tau_lo + srow + 64 * it) if ok else 0.0
-                    for it in range((MFMA_NH + 3) // 4):
-                        if 4 * it + sc < MFMA_NH:
-                            ok = 4 * it + sc < jc + 2
-                            lh[srow + 64 * it] = h_at(m_lo + srow + 64 * it) if ok else 0.0
-                # the multiply: lane (n, kq), chunk j, k group g
-                for j in range(jc):
-                    for g in range(4):
-                        for kq in range(4):
-                            xs = np.array([lx[kq * MFMA_NC + n + jc - 1 + 4 * g * MFMA_NC - j] for n in range(MFMA_SEG)])
-                            hs = np.array([lh[MFMA_SEG + i - kq + MFMA_SEG * j - 4 * g] for i in range(MFMA_SEG)])
-                            acc += np.outer(xs, hs)                       # one k of v_mfma_f32_16x16x4: O[n][i] += X(n, k) * H(k, i)
-            for n in range(MFMA_SEG):
-                for i in range(MFMA_SEG):
-                    t = 256 * tile + MFMA_SEG * n + i
-                    if t < T:
-                        out[split, t] = acc[n, i]
-    return out
+    tilesA, splitsA, tilesB, splitsB = mfma_plan(T, units, P, wgs)
+    t_split = tilesA * MFMA_TILE if tilesB > 0 else T
+    partA = np.zeros((t_split, splitsA), np.complex128)             # part[t][split]
+    partB = np.zeros((max(T - t_split, 0), splitsB), np.complex128)
+    for tile_first, tile_count, splits, part, t_base in ((0, tilesA, splitsA, partA, 0), (tilesA, tilesB, splitsB, partB, t_split)):
+        for tile in range(tile_first, tile_first + tile_count):
+            for split in range(splits):
+                jb, je = J * split // splits, J * (split + 1) // splits
+                O = mfma_wave(xt, ht, hist, tile, jb, je) if jb < je else np.zeros((16, 16), np.complex128)
+                for n in range(16):                                 # accumulator register v of lane (i, kq): O[4 kq + v][i]
+                    for i in range(16):
+                        t = MFMA_TILE * tile + 16 * n + i
+                        if t < T:
+                            part[t - t_base, split] = O[n, i]
+    return np.concatenate([partA.sum(axis=1), partB.sum(axis=1)])

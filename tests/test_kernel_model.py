@@ -56,18 +56,26 @@ def test_fused_split_row_pairing(M1, M2, R):
     assert np.all(seen == 1)
 
 
-@pytest.mark.parametrize("np_,T,splits", [(1, 5, 1), (15, 40, 1), (16, 256, 1), (17, 300, 2), (150, 257, 1), (375, 70, 3), (160, 33, 4)])
-def test_toeplitz_block_time_axis(np_, T, splits):
-    """fdl_mfma.hpp: one bin's time axis as sums of 16 x 16 Toeplitz-block products -- tiles, partition splits, stage windows, the
-    LDS image index formulas and the operand positions of the kernel, restated in numpy -- equals the direct sum
-    Y[t] = sum_m H[m] X[t - m] over the FDL history (tau > -np) and the call's blocks."""
-    from kernel_model import mfma_chunks, mfma_time_axis
+@pytest.mark.parametrize("np_,P,T,units,wgs", [(1, 1, 5, 16, 256), (15, 15, 40, 16, 256), (16, 16, 256, 16, 256), (17, 40, 300, 16, 256),
+                                               (150, 150, 257, 16, 256), (375, 375, 70, 16, 256), (160, 375, 33, 4, 256),
+                                               (100, 100, 600, 16, 32), (33, 33, 1100, 8, 16)])
+def test_toeplitz_block_time_axis(np_, P, T, units, wgs):
+    """fdl_mfma.hpp: one bin's time axis as sums of 16 x 16 Toeplitz-block products -- the transposed layouts (history, zero taps in front
+    and behind, stale finite values beyond the call), tiles, partition splits, the two-launch plan with its two partial-spectrum
+    regions, the buffer loads' byte offsets, the register sets that swap roles, the DPP shift of the X window and the MFMA operand /
+    result maps, restated in numpy -- equals the direct sum Y[t] = sum_m H[m] X[t - m] over the FDL history and the call's blocks.
+    (wgs < 256 stands in for a smaller chip so that small cases reach the two-launch branch.)"""
+    from kernel_model import mfma_chunks, mfma_hist, mfma_plan, mfma_time_axis
     rng = np.random.default_rng(1000 * np_ + T)
     H = rng.standard_normal(np_) + 1j * rng.standard_normal(np_)
-    xs = rng.standard_normal(np_ + T) + 1j * rng.standard_normal(np_ + T)          # X[tau] at index tau + np - 1 ... history first
-    X = lambda tau: xs[tau + np_ - 1]
-    got = mfma_time_axis(X, H, T, splits).sum(axis=0)
-    ref = np.array([sum(H[m] * X(t - m) for m in range(np_) if t - m > -np_) for t in range(T)])
+    hist = mfma_hist(P)
+    xs = rng.standard_normal(hist + T) + 1j * rng.standard_normal(hist + T)          # X[tau] at index tau + hist: history first
+    X = lambda tau: xs[tau + hist]
+    got = mfma_time_axis(X, H, T, P, units, wgs)
+    ref = np.array([sum(H[m] * X(t - m) for m in range(np_)) for t in range(T)])
     assert np.abs(got - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
     J = mfma_chunks(np_)
     assert 16 * (J - 1) - 15 <= np_ - 1 < 16 * J            # the last chunk is needed, one more would multiply zeros only
+    assert hist >= np_ - 1                                   # the history columns hold every block an output can depend on
+    tA, sA, tB, sB = mfma_plan(T, units, P, wgs)
+    assert tA + tB == (T + 255) // 256 and (tB == 0 or (tA * units) % wgs == 0 or tA * units > wgs - units)
