@@ -224,14 +224,18 @@ int  irb_device_quiet_end(int device);
 typedef struct irb_convolve_profile {
     double total_ms;            /* the whole call                                                           */
     double setup_ms;            /* engine look-up (or creation: engine_created), FDL reset, IR upload + transform enqueued */
-    double pack_ms;             /* calling thread: caller's audio -> pinned staging                         */
-    double unpack_ms;           /* calling thread: pinned staging -> caller's out (its share of the chunks) */
-    double unpack_helper_ms;    /* unpacking thread: the same for the other chunks                          */
-    double wait_ms;             /* calling thread blocked on output chunks' events                          */
-    double wait_helper_ms;      /* unpacking thread blocked on output chunks' events                        */
-    double stall_ms;            /* calling thread waiting for the unpacking thread at the end               */
-    double fft_in_and_mac_ms;   /* device: first forward-FFT launch -> multiply done (includes waiting for the host's packing) */
-    double fft_out_ms;          /* device: inverse FFTs + overlap-add of all chunks                          */
+    double register_ms;         /* direct form: hipHostRegister of the caller's audio and result buffers     */
+    double pack_ms;             /* staged form, calling thread: caller's audio -> pinned staging             */
+    double unpack_ms;           /* staged form, calling thread: pinned staging -> caller's out (its share of the chunks) */
+    double unpack_helper_ms;    /* staged form, unpacking thread: the same for the other chunks              */
+    double wait_ms;             /* calling thread blocked on the device (direct: the one wait of the call)   */
+    double wait_helper_ms;      /* staged form: unpacking thread blocked on output chunks' events            */
+    double stall_ms;            /* staged form: calling thread waiting for the unpacking thread at the end   */
+    double fft_in_ms;           /* device: forward FFTs of all blocks (direct: reading the caller's audio over PCIe; staged: also the
+                                   host's packing it waits for, and the multiply)                           */
+    double mac_ms;              /* device: the multiply-accumulate (direct form; -1 in the staged form)     */
+    double fft_out_ms;          /* device: inverse FFTs + overlap-add of all blocks, written to the caller's buffer / the staging */
+    int direct;                 /* 1: the kernels read / wrote the caller's (registered) memory; 0: staged copies */
     int chunks, blocks_per_chunk, pieces, steps;   /* steps = floor(La/B) + P (+1 without the reference's dropped tail); pieces = multiplies */
     int helper_thread, engine_created, mac_on_matrix_cores, mac_launches;
 } irb_convolve_profile;

@@ -38,7 +38,8 @@ def convolvePeriodic(buffer1, buffer2, processBlockSize=256, device=0, keep_refe
     reference's dropped tail (:236-238); False returns the complete linear convolution."""
     a = np.ascontiguousarray(np.atleast_2d(buffer1), np.float32)
     h = np.ascontiguousarray(np.atleast_2d(buffer2), np.float32)
-    out = np.zeros((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
+    # (every sample of `out` is written by the call -- computed, or cleared: the dropped tail, the layout error, empty inputs)
+    out = np.empty((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
     rc = _lib.lib().irb_convolve_periodic(device, planar_ptrs(a), a.shape[0], a.shape[1],
                                           planar_ptrs(h), h.shape[0], h.shape[1], processBlockSize,
                                           1 if keep_reference_tail else 0, planar_ptrs(out))

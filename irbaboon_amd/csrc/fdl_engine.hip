@@ -64,6 +64,7 @@ struct irb_fdl {
     int mfma_min_T = 512;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
     int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
+    int mfma_res = 1;                        // workgroups of it a CU holds at once (IRB_TILED_MFMA_RES)
     bool mfma_two_launch = true;             // whole rounds of workgroups + a second launch for the remaining tiles (IRB_TILED_MFMA_TWO_LAUNCH)
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
@@ -280,17 +281,21 @@ MfmaPlan mfma_plan(const irb_fdl *h, int T)
     const int ntiles = (T + irb::kMfmaTile - 1) / irb::kMfmaTile;
     const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
     const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);           // every split keeps a few chunks
-    auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, h->mfma_wgs / std::max<long>(1, wgs))); };
-    const long per_round = h->mfma_wgs / units;                                              // tiles that fill the chip once
+    const long slots = (long) h->mfma_wgs * h->mfma_res;                                     // workgroups resident at once (64 VGPRs, 34 KiB of LDS: two per CU)
+    auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, slots / std::max<long>(1, wgs))); };
+    const long per_round = h->mfma_wgs / units;                                              // tiles that give every CU one workgroup
     const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
-    if (full == 0 || full == ntiles || !h->mfma_two_launch) {
+    if (full == 0 || !h->mfma_two_launch) {
         p.tilesA = ntiles;
-        p.splitsA = ntiles * units < h->mfma_wgs ? splits_for(ntiles * units) : 1;
+        p.splitsA = ntiles * units <= h->mfma_wgs ? splits_for(ntiles * units) : 1;
         return p;
     }
+    // whole rounds: every CU holds mfma_res workgroups of 1 / mfma_res of the partitions each (one's first loads, barrier and
+    // stores run under the other's MFMAs)
     p.tilesA = full;
+    p.splitsA = std::min(by_work, h->mfma_res);
     p.tilesB = ntiles - full;
-    p.splitsB = splits_for(p.tilesB * units);
+    if (p.tilesB > 0) p.splitsB = splits_for(p.tilesB * units);
     return p;
 }
 
@@ -302,6 +307,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len;
     a.tile_first = 0; a.tile_count = 1; a.t_base = 0; a.part_T = 1;
     a.t_first = 0; a.t_count = 1; a.part2 = nullptr; a.t_split = 1; a.nq2 = 1;
+    a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
@@ -538,12 +544,15 @@ constexpr int kMaxDevices = 64;
 std::mutex g_reg_mu;
 std::vector<irb_fdl *> g_resident;                    // handles that own a mailbox (created with IRB_FDL_RESIDENT on a large-BAR device)
 std::atomic<int> g_quiet[kMaxDevices];                // threads inside a quiet section, per device
+std::atomic<bool> g_quiet_disabled{false};
 
 bool device_quiet(int dev) { return dev >= 0 && dev < kMaxDevices && g_quiet[dev].load(std::memory_order_seq_cst) > 0; }
 
 void quiet_begin(int dev)
 {
     if (dev < 0 || dev >= kMaxDevices) return;
+    static const bool off = env_int("IRB_DEVICE_QUIET", 1) == 0;        // diagnostic: what the library did before round 4 (profiles/r04_resident_vs_process.txt)
+    if (off) { g_quiet_disabled.store(true); return; }
     g_quiet[dev].fetch_add(1, std::memory_order_seq_cst);
     std::lock_guard<std::mutex> lk(g_reg_mu);
     for (irb_fdl *o : g_resident)
@@ -553,6 +562,7 @@ void quiet_begin(int dev)
 
 void quiet_end(int dev)
 {
+    if (g_quiet_disabled.load()) return;
     if (dev >= 0 && dev < kMaxDevices) g_quiet[dev].fetch_sub(1, std::memory_order_seq_cst);
 }
 
@@ -700,9 +710,55 @@ struct Unpacker {
     }
 };
 
+// The caller's pageable planar buffers made addressable by the GPU for the duration of one call (hipHostRegister: 1-2 us per range
+// on this system, tools/pin_probe.hip -- against 70-190 us for copying 4 MiB through pinned staging on one host thread).  Channels
+// that share pages (one allocation, as in a juce::AudioBuffer or a 2-D numpy array) are registered as one range.
+struct HostRanges {
+    struct Range { char *host; size_t len; char *dev; };
+    std::vector<Range> r;
+    bool add(const float *const *chan, int nch, size_t floats)
+    {
+        constexpr uintptr_t PG = 4096;
+        std::vector<std::pair<uintptr_t, uintptr_t>> hull;
+        for (int c = 0; c < nch; c++) {
+            const uintptr_t b = reinterpret_cast<uintptr_t>(chan[c]);
+            hull.emplace_back(b / PG * PG, (b + floats * sizeof(float) + PG - 1) / PG * PG);
+        }
+        std::sort(hull.begin(), hull.end());
+        for (size_t i = 0; i < hull.size();) {
+            uintptr_t lo = hull[i].first, hi = hull[i].second;
+            size_t k = i + 1;
+            while (k < hull.size() && hull[k].first <= hi) { hi = std::max(hi, hull[k].second); k++; }
+            bool covered = false;                                  // (the audio and the result may live in one allocation too)
+            for (const Range &q : r) covered = covered || (reinterpret_cast<uintptr_t>(q.host) <= lo && hi <= reinterpret_cast<uintptr_t>(q.host) + q.len);
+            if (!covered) {
+                void *d = nullptr;
+                if (hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void) hipGetLastError(); return false; }
+                r.push_back({reinterpret_cast<char *>(lo), (size_t) (hi - lo), nullptr});
+                if (hipHostGetDevicePointer(&d, reinterpret_cast<void *>(lo), 0) != hipSuccess) { (void) hipGetLastError(); return false; }
+                r.back().dev = static_cast<char *>(d);
+            }
+            i = k;
+        }
+        return true;
+    }
+    float *dev(const float *p) const
+    {
+        const char *c = reinterpret_cast<const char *>(p);
+        for (const Range &q : r) if (c >= q.host && c < q.host + q.len) return reinterpret_cast<float *>(q.dev + (c - q.host));
+        return nullptr;
+    }
+    void release()
+    {
+        for (const Range &q : r) (void) hipHostUnregister(q.host);
+        r.clear();
+    }
+    ~HostRanges() { release(); }
+};
+
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
-    std::vector<hipEvent_t> ev;                        // [0..2]: first FFT launch, multiply done, (unused); [3 + k]: output chunk k has left
+    std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -806,6 +862,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
     h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
     h->mfma_two_launch = env_int("IRB_TILED_MFMA_TWO_LAUNCH", 1) != 0;
+    h->mfma_res = std::max(1, std::min(2, env_int("IRB_TILED_MFMA_RES", 1)));       // measured (profiles/r04_mfma_stamps.txt): two per CU start late and multiply slower
     // gfx950 only: the instruction timings and the DPP / buffer-load forms the kernel is written in are that chip's
     h->mfma_capable = h->is_gfx950 && !h->stepwise && h->mfma_min_T > 0 && h->Tmax >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
     if (h->mfma_capable) {
@@ -1472,8 +1529,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         if (rc0 != IRB_OK) return rc0;
         g_offline.eng = h;
         hipError_t e = hipSuccess;
-        g_offline.ev.assign((size_t) 3 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
-        for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
+        g_offline.ev.assign((size_t) 4 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
+        for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
@@ -1482,6 +1539,74 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     if (rc != IRB_OK) return rc;
     rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
     if (rc != IRB_OK) return rc;
+    // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves (both registered for the
+    // call): no host copy at all, one launch per phase.  Taken unless registration is refused (then the staged pipeline below runs).
+    bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
+    if (env_int("IRB_OFFLINE_DIRECT", 1) != 0 && steps >= 2 && !last_piece_is_one_block) {
+        const double t_reg = now_ms();
+        HostRanges ranges;
+        float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
+        bool ok = ranges.add(audio, audio_ch, (size_t) La) && ranges.add(out, audio_ch, (size_t) Lout);
+        for (int c = 0; c < audio_ch && ok; c++) {
+            d_audio[c] = ranges.dev(audio[c]);
+            d_res[c] = ranges.dev(out[c]);
+            ok = d_audio[c] && d_res[c];
+        }
+        const long in_stride = audio_ch == 2 && ok ? (long) (d_audio[1] - d_audio[0]) : 0, out_stride = audio_ch == 2 && ok ? (long) (d_res[1] - d_res[0]) : 0;
+        if (ok) {
+            prof.register_ms = now_ms() - t_reg;
+            prof.setup_ms = t_reg - t_begin;
+            const bool device_times = g_offline_profile_events;
+            float dev_ms[3] = {0, 0, 0};
+            int pieces = 0;
+            for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
+                const int T = (int) std::min<long>(Tneed, steps - p0);
+                irb::StepArgs a = step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride);
+                a.out_stride = out_stride;
+                a.in_len = std::max<long>(0, (long) La - p0 * B);           // blocks past the audio's end are the flush: zeros
+                a.out_len = std::max<long>(0, lim - p0 * B);                 // nothing is written past the samples this call produces
+                TiledCall call;
+                rc = tiled_begin(h, a, T, &call);
+                if (rc != IRB_OK) break;
+                if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
+                rc = tiled_push(h, call, 0, T);
+                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
+                if (rc == IRB_OK) rc = tiled_mac(h, call);
+                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
+                if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
+                if (rc != IRB_OK) break;
+                tiled_end(h, call);
+                if (device_times) {
+                    (void) hipEventRecord(g.ev[3], h->stream);
+                    if (hipEventSynchronize(g.ev[3]) == hipSuccess) {
+                        float ms = 0;
+                        for (int k = 0; k < 3; k++) if (hipEventElapsedTime(&ms, g.ev[k], g.ev[k + 1]) == hipSuccess) dev_ms[k] += ms;
+                    }
+                }
+            }
+            const double t_wait = now_ms();
+            const hipError_t e = irb_sync(h);                        // also on failure: nothing may still be reading or writing the caller's memory
+            prof.wait_ms = now_ms() - t_wait;
+            ranges.release();
+            if (rc != IRB_OK) return rc;
+            if (e != hipSuccess) return fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e));
+            rc = check_status(h);
+            if (rc != IRB_OK) return rc;
+            prof.total_ms = now_ms() - t_begin;
+            prof.direct = 1;
+            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
+            prof.chunks = pieces; prof.blocks_per_chunk = Tneed; prof.pieces = pieces; prof.steps = (int) steps;
+            prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
+            {
+                const MfmaPlan pl = mfma_plan(h, (int) std::min<long>(Tneed, steps));
+                prof.mac_launches = prof.mac_on_matrix_cores ? (pl.tilesB > 0 ? 2 : 1) : 1;
+            }
+            g.prof = prof; g.have_prof = true;
+            return IRB_OK;
+        }
+        ranges.release();                                            // registration refused (read-only mapping, exotic memory): staged copies
+    }
+
     const long stride = (long) h->Tmax * h->B;
     float *const host_in = h->h_io, *const host_out = h->h_io + (size_t) audio_ch * stride;
     float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
@@ -1496,8 +1621,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         const int nio = (T + io - 1) / io;
         nio_total += nio;
         for (int k = 0; k < nio; k++)
-            if (!g.ev[3 + k]) {
-                hipError_t e = hipEventCreateWithFlags(&g.ev[3 + k], hipEventDisableTiming);
+            if (!g.ev[4 + k]) {
+                hipError_t e = hipEventCreateWithFlags(&g.ev[4 + k], hipEventDisableTiming);
                 if (e != hipSuccess) return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e));
             }
         TiledCall call;
@@ -1529,7 +1654,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         for (int k = 0; k < nio && rc == IRB_OK; k++) {
             const int first = k * io, cnt = std::min(io, T - first);
             if (tiled) rc = tiled_ifft(h, call, first, cnt);
-            if (rc == IRB_OK && hipEventRecord(g.ev[3 + k], h->stream) != hipSuccess) rc = fail(IRB_ERR_HIP, "hipEventRecord failed");
+            if (rc == IRB_OK && hipEventRecord(g.ev[4 + k], h->stream) != hipSuccess) rc = fail(IRB_ERR_HIP, "hipEventRecord failed");
         }
         if (device_times) (void) hipEventRecord(g.ev[2], h->stream);
         if (tiled && rc == IRB_OK) tiled_end(h, call);
@@ -1537,7 +1662,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         // ---- unpack: chunk k of this piece -> out, even k here, odd k on the unpacking thread
         auto unpack = [&](int k, int who) -> int {
             const double t0 = now_ms();
-            hipError_t e = hipEventSynchronize(g.ev[3 + k]);
+            hipError_t e = hipEventSynchronize(g.ev[4 + k]);
             if (e != hipSuccess) return fail(IRB_ERR_HIP, "waiting for an output chunk: %s", hipGetErrorString(e));
             const double t1 = now_ms();
             const int first = k * io, cnt = std::min(io, T - first);
@@ -1573,7 +1698,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     prof.total_ms = now_ms() - t_begin;
     prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1];
     prof.wait_ms = wait_ms[0]; prof.wait_helper_ms = wait_ms[1];
-    prof.fft_in_and_mac_ms = device_times ? dev_ms[0] : -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;
+    prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;   // (staged: the multiply is inside fft_in_ms)
     prof.chunks = nio_total; prof.blocks_per_chunk = io; prof.pieces = pieces; prof.steps = (int) steps;
     prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
     {
@@ -1594,7 +1719,7 @@ int irb_device_quiet_begin(int device)
 int irb_device_quiet_end(int device)
 {
     if (device < 0 || device >= kMaxDevices) return fail(IRB_ERR_ARG, "device %d out of range", device);
-    if (!device_quiet(device)) return fail(IRB_ERR_STATE, "irb_device_quiet_end without a matching begin");
+    if (!device_quiet(device) && !g_quiet_disabled.load()) return fail(IRB_ERR_STATE, "irb_device_quiet_end without a matching begin");
     quiet_end(device);
     return IRB_OK;
 }

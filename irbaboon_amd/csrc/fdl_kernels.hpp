@@ -76,6 +76,9 @@ struct StepArgs {
     // k_ifft_ola_run: blocks from t_split on have their partial spectra in part2[s][t - t_split][nq2][M] (t_split = T: all in `part`)
     const float2 *part2;
     int           t_split, nq2;
+    // ... and the samples that exist behind `in` / may be written behind `out`, per stream (irb_convolve_periodic lets these kernels read
+    // the caller's audio and write the caller's result buffer in place: blocks past the end read as zeros / are cut off)
+    long          in_len, out_len;
 };
 
 #ifdef IRB_STAMPS
@@ -1083,7 +1086,7 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     const int j = a.t_first + item % a.t_count, s = item / a.t_count;
     TwiddleStage<N, kWave * NF> tws;
     tws.load(a.tw);
-    if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
+    if (live) wave_load_block_upto<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, a.in_len - (long) j * a.B, l_buf[wave], lane);
     tws.store(l_tw);
     __syncthreads();
     if (!live) return;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     const bool live = j < a.t_first + a.t_count;
     TwiddleStage<N, kWave * NBW> tws;
     tws.load(a.tw);
-    if (live) wave_load_block<M>(a.in + (size_t) s * a.in_stride + (size_t) j * a.B, a.B, l_buf[wave], lane);
+    if (live) wave_load_block_upto<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, a.in_len - (long) j * a.B, l_buf[wave], lane);
     tws.store(l_tw);
     __syncthreads();
     if (live) {
@@ -191,15 +191,22 @@ __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdg
         }
     };
     // chunk j is multiplied out of (xc, hc); (xn, hn) -- loaded for chunk j + 1 -- becomes its window; then (xc, hc) is reloaded for chunk j + 2
+#ifndef IRB_MFMA_EXP
+#define IRB_MFMA_EXP 0                                 // diagnostic builds (tools/mfma_stamps.hip): 1 no window shift, 2 no loads in the loop -- timing only, wrong sums
+#endif
     auto step = [&](int j, float2 (&xc)[4], float2 (&hc)[4], float2 (&xn)[4]) {
         __builtin_amdgcn_sched_barrier(0);
         multiply(xc, hc);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(IRB_MFMA_EXP & 1)) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) xn[g] = make_float2(shift_in(xn[g].x, xc[g].x), shift_in(xn[g].y, xc[g].y));
+            for (int g = 0; g < 4; g++) xn[g] = make_float2(shift_in(xn[g].x, xc[g].x), shift_in(xn[g].y, xc[g].y));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        load_x(xc, vx_new, j + 2);                     // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
-        load_h(hc, j + 2);
+        if constexpr (!(IRB_MFMA_EXP & 2)) {
+            load_x(xc, vx_new, j + 2);                 // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
+            load_h(hc, j + 2);
+        }
     };
     load_x(xa, vx_win, jb);
     load_h(ha, jb);
@@ -218,7 +225,7 @@ __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdg
 // stream (a call may be multiplied in two launches -- whole rounds of workgroups, then the remaining tiles with more partition
 // splits -- each with its own partial-spectrum region; see launch_tiled).
 template <int N>
-__global__ __launch_bounds__(kMfmaThreads, 2) void k_cmac_mfma(StepArgs a)
+__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cmac_mfma(StepArgs a)
 {
     constexpr int M = N / 2;
     static_assert(M % kMfmaBins == 0, "bins per workgroup");

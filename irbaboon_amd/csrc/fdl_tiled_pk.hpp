@@ -237,11 +237,12 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
     const float *y = reinterpret_cast<const float *>(buf);
     if (wave >= 1) {
         const float *yp = reinterpret_cast<const float *>(l_buf[wave - 1]);
-        float *out = a.out + (size_t) s * a.out_stride + (size_t) j * a.B;
+        float *out = a.out + (long) s * a.out_stride + (long) j * a.B;
+        const long room = a.out_len - (long) j * a.B;              // samples of this block that may be written (a result buffer's ragged end)
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
             const int n = lane + i * kWave;
-            if (n < a.B) out[n] = y[n] * scale + yp[a.B + n] * scale;
+            if (n < a.B && n < room) out[n] = y[n] * scale + yp[a.B + n] * scale;
         }
     }
     if (j == a.T - 1) {

@@ -192,6 +192,19 @@ __device__ __forceinline__ void wave_load_block(const float *__restrict__ x, int
     wave_sync();
 }
 
+// the same for a block of which only the first `have` samples exist behind x (a signal's last, ragged block; have <= 0: none --
+// nothing is read then)
+template <int M>
+__device__ __forceinline__ void wave_load_block_upto(const float *__restrict__ x, int B, long have, float2 *z, int lane)
+{
+    if (have >= B) { wave_load_block<M>(x, B, z, lane); return; }
+    if (have > 0) { wave_load_block<M>(x, (int) have, z, lane); return; }
+    constexpr int N = 2 * M;
+    float *zf = reinterpret_cast<float *>(z);
+    for (int n = lane; n < N; n += kWave) zf[n] = 0.0f;
+    wave_sync();
+}
+
 // Forward split of Z = FFT_M(z) into the packed spectrum of the N real samples (unnormalised, as
 // performRealOnlyForwardTransform leaves it, reference fp/convolution.cpp:123,144), written through
 // `store(bin, value)` (global and/or LDS).  Bin 0 = (DC, Nyquist).  A lane produces bins b and M-b together,

@@ -228,17 +228,19 @@ def mfma_taps(P):
     return MFMA_SEG * (mfma_chunks(P) + 3)
 
 
-def mfma_plan(T, units, P, wgs=256, min_chunks=6):
-    """fdl_engine.hip: mfma_plan -- (tilesA, splitsA, tilesB, splitsB): whole rounds of workgroups unsplit, then the remaining tiles
-    with their partitions split; units = streams x bin groups = workgroups per tile at one split"""
+def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
+    """fdl_engine.hip: mfma_plan -- (tilesA, splitsA, tilesB, splitsB): whole rounds of workgroups (res per CU, each 1 / res of the
+    partitions), then the remaining tiles with their partitions split over all resident slots; units = streams x bin groups =
+    workgroups per tile at one split"""
     ntiles = (T + MFMA_TILE - 1) // MFMA_TILE
     by_work = max(1, mfma_chunks(P) // min_chunks)
-    splits_for = lambda w: max(1, min(by_work, wgs // max(1, w)))
+    splits_for = lambda w: max(1, min(by_work, wgs * res // max(1, w)))
     per_round = wgs // units
     full = ntiles // per_round * per_round if per_round > 0 else ntiles
-    if full == 0 or full == ntiles:
-        return ntiles, (splits_for(ntiles * units) if ntiles * units < wgs else 1), 0, 1
-    return full, 1, ntiles - full, splits_for((ntiles - full) * units)
+    if full == 0:
+        return ntiles, (splits_for(ntiles * units) if ntiles * units <= wgs else 1), 0, 1
+    tilesB = ntiles - full
+    return full, min(by_work, res), tilesB, (splits_for(tilesB * units) if tilesB > 0 else 1)
 
 
 def mfma_layouts(X, H, T, P):

@@ -460,10 +460,13 @@ def test_resident_server_does_not_stall_other_handles():
     lines = [f"{k}: {v * 1e3:.2f} ms" for k, v in marks.items()]
     lines.append(f"adapter A: {n_done} callbacks of 256 samples ({cb_during - 200} of them while the main thread worked), median {np.median(cb) * 1e3:.1f} us, "
                  f"p99 {np.percentile(cb, 99) * 1e3:.1f} us, max {cb.max() * 1e3:.1f} us; launches in that window {c1[1] - c0[1]}, waits {c1[2] - c0[2]}")
+    unprotected = os.environ.get("IRB_DEVICE_QUIET") == "0"      # diagnostic run: quiet sections switched off, times recorded, not asserted
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "resident_vs_process.txt"), "w") as f:
+    with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "resident_vs_process" + ("_unprotected" if unprotected else "") + ".txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    if unprotected:
+        return
     # a stall behind the server would be its lifetime cap (250 ms) per device-wide wait: dozens of frees -> seconds
     assert sum(marks.values()) < 1.5, marks
     assert cb.max() < 100.0, cb.max()                            # ms: no callback was held up for a server lifetime either

@@ -78,4 +78,4 @@ def test_toeplitz_block_time_axis(np_, P, T, units, wgs):
     assert 16 * (J - 1) - 15 <= np_ - 1 < 16 * J            # the last chunk is needed, one more would multiply zeros only
     assert hist >= np_ - 1                                   # the history columns hold every block an output can depend on
     tA, sA, tB, sB = mfma_plan(T, units, P, wgs)
-    assert tA + tB == (T + 255) // 256 and (tB == 0 or (tA * units) % wgs == 0 or tA * units > wgs - units)
+    assert tA + tB == (T + 255) // 256 and (tB == 0 or (tA * units) % wgs == 0)
