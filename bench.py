@@ -234,8 +234,7 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
             min_bytes = float(I * C) * (2 * e.info.partitions + T) * e.info.fft_len * 4.0
             ent["min_traffic_GBps"] = round(min_bytes / ms / 1e6, 1)
             ent["frac_of_hbm_peak_min_traffic"] = round(min_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)
-            ent["mac_kernel"] = ("k_cmac_mfma (v_mfma_f32_16x16x4_f32: Toeplitz blocks along the time axis)" if T >= 512 and "IRB_TILED_MFMA_MIN_T" not in os.environ
-                                 else "k_cmac_tiled_pk (v_pk_fma_f32)")
+            ent["mac_kernel"] = e.mac_kernel_name(T)        # what the handle selected (irb_fdl_mac_kernel_name), not a guess
             ent["roofline_note"] = ("whole call (forward FFTs + MAC + inverse FFTs / overlap-add) against the fp32 peak (157.3 TFLOP/s, vector ALU "
                                     "and exact-fp32 matrix instructions alike); MAC flops only: 8 per complex bin, P partitions, N/2 packed bins, "
                                     "T blocks.  min_traffic: H and the FDL window read once per call -- the binding side of HBM-sized batches "
@@ -255,9 +254,79 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     run("rt_layout_1024_stereo_instances_mono_ir", 1024, 2, 256, 96000, 1, 100,
         "stereo audio, IR channel 0 for both channels (the plug-in's real-time layout, Source/PluginProcessor.cpp:485): "
         "paired kernel loads each IR row once for both channels (3 rows per partition instead of 4)", ir_ch=1)
+    res["configs[0]_one_shot"] = one_shot(dev, np, decaying_ir, white_noise, 1, 1, 256, 4096, 480000,
+                                          "configs[0] (the reference's CPU plumbing case: mono, B=256, Lh=4096, 10 s of audio) through the drop-in function")
+    res["configs[1]_one_shot"] = one_shot(dev, np, decaying_ir, white_noise, 1, 1, 256, 96000, 960000,
+                                          "configs[1] (mono, B=256, 2 s IR, 20 s of audio) through the drop-in function")
     res["rt_processBlock"] = rt_process_block(dev, np)
     res.update(config5(dev, np))
     return res
+
+
+def one_shot(dev, np, decaying_ir, white_noise, Ca, Ci, Bk, Lh, La, note, reps=21):
+    """fp::convolution::convolvePeriodic (fp/convolution.hpp:31) as a maintainer binds it: irb_convolve_periodic, whole signal in, whole
+    signal out, PAGEABLE host buffers, wall clock.  Two figures: the Python mirror convolvePeriodic(...) (a fresh result array per call,
+    as a caller of the reference's function gets a fresh AudioBuffer) and the C ABI itself with the caller's buffers reused; plus the
+    library's own breakdown of the median-like call (irb_convolve_last_profile: host phases and hipEvent intervals)."""
+    import ctypes as C
+    from irbaboon_amd import _lib, convolvePeriodic
+    from irbaboon_amd._lib import planar_ptrs
+    x = np.stack([white_noise(4000 + c, La) for c in range(Ca)])
+    h = np.stack([decaying_ir(4100 + c, Lh) for c in range(Ci)])
+    lib = _lib.lib()
+    lib.irb_convolve_profile_events(0)
+    convolvePeriodic(x, h, Bk, device=dev)                           # builds the calling thread's engine
+    ta, tb, profs = [], [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        convolvePeriodic(x, h, Bk, device=dev)
+        ta.append(time.perf_counter() - t0)
+    out = np.zeros((Ca, La + Lh - 1), np.float32)
+    xp, hp, op = planar_ptrs(x), planar_ptrs(h), planar_ptrs(out)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rc = lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
+        tb.append(time.perf_counter() - t0)
+        if rc != 0:
+            raise SystemExit("irb_convolve_periodic failed: " + lib.irb_last_error().decode())
+    lib.irb_convolve_profile_events(1)                               # a few more calls with the device-event part of the profile on
+    for _ in range(7):
+        lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
+        p = _lib.ConvolveProfile()
+        lib.irb_convolve_last_profile(C.byref(p))
+        profs.append(p.as_dict())
+    lib.irb_convolve_profile_events(0)
+    med = {k: (round(float(np.median([p[k] for p in profs])), 4) if isinstance(profs[0][k], float) else int(np.median([p[k] for p in profs]))) for k in profs[0]}
+    ms = float(np.median(tb)) * 1e3
+    ent = {"wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(min(tb) * 1e3, 4),
+           "Msamples_per_s": round(Ca * La / ms / 1e3, 1), "samples": Ca * La, "calls_timed": reps,
+           "pcie_bytes": 4 * (Ca * La + Ca * (La + Lh - 1) + Ci * Lh), "pcie_GBps_both_ways": round(4 * (Ca * La + Ca * (La + Lh - 1)) / ms / 1e6, 2),
+           "breakdown_ms": med,
+           "breakdown_note": "irb_convolve_last_profile, medians over 7 further calls with device events on (those calls wait once more per piece, so "
+                             "their total_ms runs a few us above wall_ms_c_abi).  direct=1: the kernels read the caller's audio and write the caller's "
+                             "result buffer themselves (both registered for the call; no host copy): fft_in_ms / fft_out_ms are PCIe-bound, mac_ms is "
+                             "the multiply over ALL blocks of the signal in mac_launches launches (chunks = pieces = multiplies, blocks_per_chunk = "
+                             "blocks per multiply)",
+           "note": note + "; pageable numpy buffers, wall clock, engine cached from the first call"}
+    lib.irb_release_cached_plans()
+    return ent
+
+
+def cpu_one_shot(np, ent, Ca, Ci, Bk, Lh, La, reps):
+    """part of the cpu_baseline leg: the oracle's time for the same one-shot call (one core), written into the entry"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from irbaboon_amd.synth import decaying_ir, white_noise
+    oracle.use_native()
+    x = np.stack([white_noise(4000 + c, La) for c in range(Ca)])
+    h = np.stack([decaying_ir(4100 + c, Lh) for c in range(Ci)])
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.convolve_periodic(x, h, Bk)
+        ts.append(time.perf_counter() - t0)
+    ent["cpu_oracle_ms_1_core"] = round(float(np.median(ts)) * 1e3, 2)
+    ent["speedup_vs_cpu_oracle"] = round(ent["cpu_oracle_ms_1_core"] / ent["wall_ms_c_abi"], 1)
 
 
 def rt_process_block(dev, np):
@@ -421,8 +490,11 @@ def main():
 
     I, K, W = args.instances, args.steps, args.warmup
 
+    setup_s = {}
+
     def build_shard(slot_dev):
         slot, dev = slot_dev
+        t_setup = time.perf_counter()
         shard_id = rank if mode == "ranks" else slot
         eng = FdlEngine(I, 1, B, LH, max_blocks_per_call=NB, device=dev)
         lo = shard_id * I             # weak scaling: every GPU owns I instances of its own, distinct IRs
@@ -430,6 +502,8 @@ def main():
             eng.set_ir(i, decaying_ir(18000 + 2 * (lo + i), LH))
         x = np.stack([white_noise(2000 + 2 * (lo + i), NB * B) for i in range(I)])
         eng.upload(eng.device_io()[0], x)
+        eng.synchronize()
+        setup_s[slot] = round(time.perf_counter() - t_setup, 3)      # engine + 2048 IR uploads and transforms + audio upload, per device
         return (eng, lo), x
 
     if len(devices) > 1:              # one host thread per device for the set-up (one caller thread per handle)
@@ -483,11 +557,14 @@ def main():
         ev_ms_max, ev_ms_min = max(ev_ms), min(ev_ms)
 
     total_samples = float(I) * world * B * K
-    # `value`: all ranks' samples over the slowest device's K steps as its own hipEvents saw them (recorded on the stream the
-    # kernels run on, before the first and after the last of the K launches).  The host wall clock around the same region,
-    # barrier and device syncs included, is reported beside it; with 8 engines in one process it carries 8 sync calls.
-    step_ms = ev_ms_max / K
-    value = total_samples / (ev_ms_max * 1e-3) / 1e6
+    # `value`: all ranks' samples over the host wall clock around the K timed steps, bracketed by barrier + device synchronisation on both
+    # sides, max over ranks (the contract's clock).  The slowest device's own hipEvents around its K launches (recorded on the stream the
+    # kernels run on) are reported beside it and feed the roofline entry: on one GPU the two agree to ~0.1 %; a run in which the
+    # wall clock exceeds the device time by more than 5 % has host overhead inside the timed region and is refused.
+    step_ms = wall / K * 1e3
+    value = total_samples / wall / 1e6
+    if world == 1 and wall * 1e3 > 1.05 * ev_ms_max:
+        raise SystemExit(f"host wall clock {wall * 1e3:.3f} ms exceeds the device's event time {ev_ms_max:.3f} ms by more than 5 %: not a clean measurement")
     three = bool(os.environ.get("IRB_SPLIT_3LAUNCH", "0") not in ("", "0"))
     launches_per_step = 1 if (info.splits <= 1 or not three) else 3
     kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step; the slowest device
@@ -508,9 +585,10 @@ def main():
     out = {
         "metric": "Msamples/s (48 kHz, 256-blk, 2 s IR); achieved HBM GB/s vs roofline",
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(step_ms, 4), "ms_per_step_wall": round(wall / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "n_gpus_visible": ndev, "timing": "max over devices of hipEvent time around the K timed launches (ms_per_step); host wall clock "
-                                          "around the same region incl. barrier and syncs (ms_per_step_wall)",
+        "ms_per_step": round(step_ms, 4), "ms_per_step_device_events": round(ev_ms_max / K, 4), "higher_is_better": True, "scaling": "weak",
+        "n_gpus_visible": ndev, "timing": "host wall clock around the K timed steps, barrier + device sync on both sides, max over ranks (value, "
+                                          "ms_per_step); max over devices of the hipEvent time around the same K launches (ms_per_step_device_events, roofline.kernel_ms)",
+        "setup_s_per_device": [setup_s[k] for k in sorted(setup_s)],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1] geometry (mono, B={B}, Lh={LH}, P={info.partitions}, N={info.fft_len}) "
                                f"x {I} independent instances per GPU, streaming: 1 block per instance per step",
@@ -558,8 +636,9 @@ def main():
             eng.close()
         out["other_configs"] = other_configs(dev, np, FdlEngine, decaying_ir, white_noise)
 
-    if solo and not args.no_pmc:
-        # every engine of this process is closed by now: the child runs need the HBM
+    # rank 0 of ANY world size: the in-session HBM traffic measurement (on its first device, after its engines are closed -- the
+    # child runs need the HBM) and the CPU baseline, so that an N > 1 line carries the same keys as the N = 1 line
+    if rank == 0 and not args.no_pmc:
         for eng, _ in engines:
             eng.close()
         measured, note = measure_traffic(I, devices[0])
@@ -568,9 +647,12 @@ def main():
             out["roofline"]["traffic_source"] = note
         else:
             out["roofline"]["traffic_source"] = (out["roofline"]["traffic_source"] or "none") + f"; in-session measurement unavailable: {note}"
-    if solo and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         out["cpu_baseline_all_cores"] = cpu_baseline_multicore(out["cpu_baseline"], min(4.0, args.cpu_seconds))
+        if "other_configs" in out:                    # the oracle's time for the two one-shot calls, beside the GPU's (same leg: the oracle is the CPU baseline)
+            cpu_one_shot(np, out["other_configs"]["configs[0]_one_shot"], 1, 1, 256, 4096, 480000, 5)
+            cpu_one_shot(np, out["other_configs"]["configs[1]_one_shot"], 1, 1, 256, 96000, 960000, 3)
     for eng, _ in engines:
         eng.close()
     if ranks:

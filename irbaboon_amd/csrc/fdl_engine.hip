@@ -419,7 +419,7 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
         if (first < 0) first += h->R;
         h->n_launches++;
         const dim3 grid(h->xt_hist / 16, h->M >= 64 ? h->M / 64 : 1, h->S);
-        FOR_N(h->N, irb::k_rows_to_columns<NN / 2><<<grid, dim3(256), 0, h->stream>>>(h->d_X, (long) h->R * h->M, first, h->R, h->xt_hist,
+        FOR_N(h->N, irb::k_rows_to_columns<NN / 2, true><<<grid, dim3(256), 0, h->stream>>>(h->d_X, (long) h->R * h->M, first, h->R, h->xt_hist,
                                                                                        h->d_Xt, (long) h->M * h->xt_len, h->xt_len, 0, h->xt_hist));
         HIP_TRY(hipGetLastError());
     }
@@ -519,7 +519,7 @@ int launch_ht(irb_fdl *h, int first_set, int nsets, int np)
     h->n_launches++;
     const int nrows = h->ht_len - 16;
     const dim3 grid(nrows / 16, h->M >= 64 ? h->M / 64 : 1, nsets);
-    FOR_N(h->N, irb::k_rows_to_columns<NN / 2><<<grid, dim3(256), 0, h->stream>>>(h->d_H + (size_t) first_set * h->Ppad * h->M, (long) h->Ppad * h->M, 0, 0, np,
+    FOR_N(h->N, irb::k_rows_to_columns<NN / 2, false><<<grid, dim3(256), 0, h->stream>>>(h->d_H + (size_t) first_set * h->Ppad * h->M, (long) h->Ppad * h->M, 0, 0, np,
                                                                                    h->d_Ht + (size_t) first_set * h->M * h->ht_len, (long) h->M * h->ht_len, h->ht_len, 16, nrows));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
@@ -715,29 +715,30 @@ struct Unpacker {
 // that share pages (one allocation, as in a juce::AudioBuffer or a 2-D numpy array) are registered as one range.
 struct HostRanges {
     struct Range { char *host; size_t len; char *dev; };
-    std::vector<Range> r;
-    bool add(const float *const *chan, int nch, size_t floats)
+    std::vector<std::pair<uintptr_t, uintptr_t>> hull;            // page hulls collected by add()
+    std::vector<Range> r;                                          // what commit() registered
+    void add(const float *const *chan, int nch, size_t floats)
     {
         constexpr uintptr_t PG = 4096;
-        std::vector<std::pair<uintptr_t, uintptr_t>> hull;
         for (int c = 0; c < nch; c++) {
             const uintptr_t b = reinterpret_cast<uintptr_t>(chan[c]);
-            hull.emplace_back(b / PG * PG, (b + floats * sizeof(float) + PG - 1) / PG * PG);
+            if (floats > 0) hull.emplace_back(b / PG * PG, (b + floats * sizeof(float) + PG - 1) / PG * PG);
         }
+    }
+    // hulls that touch or overlap (channels of one allocation; an audio buffer and a result buffer that share a page) become ONE
+    // registration: the runtime refuses ranges that overlap a registered one
+    bool commit()
+    {
         std::sort(hull.begin(), hull.end());
         for (size_t i = 0; i < hull.size();) {
             uintptr_t lo = hull[i].first, hi = hull[i].second;
             size_t k = i + 1;
             while (k < hull.size() && hull[k].first <= hi) { hi = std::max(hi, hull[k].second); k++; }
-            bool covered = false;                                  // (the audio and the result may live in one allocation too)
-            for (const Range &q : r) covered = covered || (reinterpret_cast<uintptr_t>(q.host) <= lo && hi <= reinterpret_cast<uintptr_t>(q.host) + q.len);
-            if (!covered) {
-                void *d = nullptr;
-                if (hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void) hipGetLastError(); return false; }
-                r.push_back({reinterpret_cast<char *>(lo), (size_t) (hi - lo), nullptr});
-                if (hipHostGetDevicePointer(&d, reinterpret_cast<void *>(lo), 0) != hipSuccess) { (void) hipGetLastError(); return false; }
-                r.back().dev = static_cast<char *>(d);
-            }
+            void *d = nullptr;
+            if (hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterMapped) != hipSuccess) { (void) hipGetLastError(); return false; }
+            r.push_back({reinterpret_cast<char *>(lo), (size_t) (hi - lo), nullptr});
+            if (hipHostGetDevicePointer(&d, reinterpret_cast<void *>(lo), 0) != hipSuccess) { (void) hipGetLastError(); return false; }
+            r.back().dev = static_cast<char *>(d);
             i = k;
         }
         return true;
@@ -750,8 +751,9 @@ struct HostRanges {
     }
     void release()
     {
-        for (const Range &q : r) (void) hipHostUnregister(q.host);
+        for (const Range &q : r) if (hipHostUnregister(q.host) != hipSuccess) (void) hipGetLastError();   // (a refused call must not leave its error for the next launch check)
         r.clear();
+        hull.clear();
     }
     ~HostRanges() { release(); }
 };
@@ -759,6 +761,8 @@ struct HostRanges {
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
     std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
+    hipStream_t s_ir = nullptr;                        // the IR's upload and transforms run beside the audio's forward FFTs ...
+    hipEvent_t ev_ir = nullptr;                        // ... and join the engine's stream before the multiply
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -769,10 +773,12 @@ struct OfflineEngineGuard {
         DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
         (void) hipSetDevice(eng->device);
         (void) irb_sync(eng);
+        if (s_ir) { (void) hipStreamSynchronize(s_ir); (void) hipStreamDestroy(s_ir); s_ir = nullptr; }
         irb_fdl_destroy(eng);
         eng = nullptr;
         for (auto &e : ev) if (e) (void) hipEventDestroy(e);
         ev.clear();
+        if (ev_ir) { (void) hipEventDestroy(ev_ir); ev_ir = nullptr; }
     }
     ~OfflineEngineGuard() { release(); }
 };
@@ -1531,14 +1537,33 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         hipError_t e = hipSuccess;
         g_offline.ev.assign((size_t) 4 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
         for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_ir, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev_ir, hipEventDisableTiming);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
     OfflineEngineGuard &g = g_offline;
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
-    rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
-    if (rc != IRB_OK) return rc;
+    {
+        // The IR's upload, partition FFTs and transposes (a chain of ~8 short device operations, ~50 us with their launch gaps) touch
+        // nothing the audio's forward FFTs touch: they run on a stream of their own, beside the first of those, and the engine's
+        // stream waits for them in front of the multiply (tiled_mac's first launch is behind this event wait for every call below).
+        // (No ordering against the reset is needed: it clears the FDL, the IR set-up writes the IR tables; the previous call on this
+        // engine has been waited for before it returned.)
+        hipStream_t main_stream = h->stream;
+        h->stream = g.s_ir;
+        rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
+        hipError_t e = hipSuccess;
+        if (rc == IRB_OK && (e = hipEventRecord(g.ev_ir, g.s_ir)) != hipSuccess) rc = fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
+        h->stream = main_stream;
+        if (rc != IRB_OK) { (void) hipStreamSynchronize(g.s_ir); return rc; }
+    }
+    // every path below calls this in front of its multiply
+    auto join_ir = [&]() -> int {
+        hipError_t e = hipStreamWaitEvent(h->stream, g.ev_ir, 0);
+        return e == hipSuccess ? IRB_OK : fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
+    };
     // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves (both registered for the
     // call): no host copy at all, one launch per phase.  Taken unless registration is refused (then the staged pipeline below runs).
     bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
@@ -1546,7 +1571,9 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         const double t_reg = now_ms();
         HostRanges ranges;
         float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
-        bool ok = ranges.add(audio, audio_ch, (size_t) La) && ranges.add(out, audio_ch, (size_t) Lout);
+        ranges.add(audio, audio_ch, (size_t) La);
+        ranges.add(out, audio_ch, (size_t) Lout);
+        bool ok = ranges.commit();
         for (int c = 0; c < audio_ch && ok; c++) {
             d_audio[c] = ranges.dev(audio[c]);
             d_res[c] = ranges.dev(out[c]);
@@ -1571,6 +1598,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
                 rc = tiled_push(h, call, 0, T);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
+                if (rc == IRB_OK) rc = join_ir();
                 if (rc == IRB_OK) rc = tiled_mac(h, call);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
                 if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
@@ -1646,6 +1674,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         }
         if (rc != IRB_OK) break;
         // ---- the multiply; a one-block call (a signal shorter than a block with a one-partition IR) is a plain step
+        rc = join_ir();
+        if (rc != IRB_OK) break;
         if (tiled) rc = tiled_mac(h, call);
         else { rc = launch_step(h, a); if (rc == IRB_OK) h->t += 1; }
         if (rc != IRB_OK) break;

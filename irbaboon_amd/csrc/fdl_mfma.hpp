@@ -15,22 +15,18 @@
 // rest went to the first stage's burst, ~700 cycles per barrier round, a window re-loaded per stage and LDS operand reads
 // between the MFMAs.  Here the two operands are kept a SECOND time in the layout the instruction wants, written once by the
 // kernels that produce them:
-//     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin (k_push_fft_batch_t; the blocks before the call's
-//                                    first one sit in [0, xt_hist): k_xt_history rebuilds them from the ring when there are any)
+//     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin, permuted inside every segment of 16 blocks (mfma_xt_pos)
+//                                    (k_push_fft_batch_t; the blocks before the call's first one sit in [0, xt_hist): rebuilt from
+//                                    the ring by k_rows_to_columns when there are any)
 //     Ht[set][bin][16 + m]           the IR spectra with the tap index contiguous per bin, 16 zero taps in front, zeros behind
 //                                    (k_rows_to_columns at irb_fdl_set_ir*)
 // A wave owns ONE bin of one tile of 256 output blocks and one range of chunks, and nothing it reads is shared with another
-// wave through LDS: per chunk it issues 16 MFMAs and
-//   * 4 buffer loads of 8 B per lane for the H operand: lane (i, kq), k group g reads tap 16 j + i - 4 g - kq -- 31 consecutive taps
-//     of its bin, 2-3 cache lines, the same for every tile (L2 hits); negative and too large taps are the layout's zeros;
-//   * 4 buffer loads for the ONE new row of 16 blocks the X operand needs: operand lane (n, kq) of chunk j + 1 holds
-//     Xc[s0 + n - j - 1][4 g + kq], which is what lane (n - 1, kq) held for chunk j -- a DPP row shift (v_mov_b32 row_shr:1) moves the
-//     window along, and the lanes n = 0, which have no left neighbour, keep the freshly loaded value (bound_ctrl off).
-// Loads are issued one chunk of MFMAs ahead of their use into the register set the previous chunk has just released (two sets swap
-// roles, the loop is unrolled by two: no copies); the row step sits in an SGPR and the k group in the instruction's immediate
-// offset, so a chunk costs 8 VMEM + 8 DPP + a handful of scalar instructions next to its 16 MFMAs, in ~50 VGPRs.  The only LDS use
-// and the only barrier are at the end: the 256 x 16 results of the sixteen waves (bins) of a workgroup are transposed so that each
-// partial-spectrum row leaves as one whole 128-byte line (part[s][t][split][M], summed over splits by k_ifft_ola_run).
+// wave through LDS memory.  Per chunk it issues 16 MFMAs, THREE small loads (one of the chunk's 31 taps by half the lanes, two of 16
+// bytes by the four lanes that start a new segment of the X window), 8 ds_bpermute that hand the taps to the lanes that multiply with
+// them, and 8 DPP moves that shift the X window by one segment -- see mfma_chunk_run.  The row step of a load sits in an SGPR, the
+// constant part in the instruction's immediate offset; ~60 VGPRs.  The only LDS memory and the only barrier are at the end: the
+// 256 x 16 results of the sixteen waves (bins) of a workgroup are transposed so that each partial-spectrum row leaves as one whole
+// 128-byte line (part[s][t][split][M], summed over splits by k_ifft_ola_run).
 //
 // Not bit-identical to the vector kernels (another summation order); parity with the oracle at the same tolerance (tests).
 // The index arithmetic (tiles, splits, operand positions, the shifting window, the transposed layouts) is restated in
@@ -40,6 +36,10 @@
 // axis than in the reference; finite input is unaffected.  Xt is zeroed at create and only ever holds spectra, so the blocks
 // a tile reads beyond the end of a call are finite.
 #pragma once
+
+#ifndef IRB_MFMA_EXP
+#define IRB_MFMA_EXP 0                                 // diagnostic builds (tools/mfma_stamps.hip): 2 = no loads in the loop -- timing only, wrong sums
+#endif
 
 namespace irb {
 
@@ -59,6 +59,10 @@ __host__ __device__ constexpr int mfma_hist(int P) { return kMfmaSeg * (mfma_chu
 // taps per bin row of Ht: 16 zeros, the taps, zeros up to the last index the run-ahead loads read (16 + 16 (J + 1) + 15)
 __host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chunks(P) + 3); }
 
+// position of block t inside its segment of 16 in Xt: [t % 4][t / 4 % 4] instead of time order, so that the four k groups an
+// operand lane (n, kq) needs -- blocks 4 g + kq, g = 0 .. 3, of one segment -- are 32 contiguous bytes
+__host__ __device__ constexpr int mfma_xt_pos(int t) { return (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3); }
+
 // ---------------------------------------------------------------------------------------------
 // k_rows_to_columns: rows [r0, r0 + nrows) of a [row][M] spectrum array (ring addressed: physical row (first + r) mod R) become
 // columns [c0 + r] of a [M][ldc] array; rows at or beyond `valid` are written as zeros.  Used for Ht (IR spectra -> tap-contiguous,
@@ -66,7 +70,7 @@ __host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chu
 // A workgroup transposes 16 rows x 64 bins through LDS: 512-byte pieces in, whole 128-byte lines out.
 // grid = (ceil(nrows / 16), M / 64 or 1, sets), block = 256.
 // ---------------------------------------------------------------------------------------------
-template <int M>
+template <int M, bool PERM>
 __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restrict__ src, long src_set_stride, int first, int R, int valid,
                                                           float2 *__restrict__ dst, long dst_set_stride, int ldc, int c0, int nrows)
 {
@@ -88,7 +92,9 @@ __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restric
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * BW; e += 256) {
         const int b = e / 16, r = e % 16;
-        if (r0 + r < nrows) d[(size_t) (b0 + b) * ldc + c0 + r0 + r] = l_t[r][b];
+        // PERM (Xt): inside each group of 16 columns position q holds row mfma_xt_pos(q) (a 4 x 4 transpose: its own inverse; c0, r0
+        // and nrows are multiples of 16 there)
+        if (r0 + r < nrows) d[(size_t) (b0 + b) * ldc + c0 + r0 + r] = l_t[PERM ? mfma_xt_pos(r) : r][b];
     }
 }
 
@@ -126,24 +132,36 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         wave_split_forward<M>(lb, l_tw, lane, [&](int b, float2 v) { dst[b] = v; lb[b] = v; });
     }
     __syncthreads();
-    // Xt[s][bin][xt_hist + j0 .. + NBW): thread -> (bin, piece of 4 blocks)
-    constexpr int Q = NBW >= 4 ? NBW / 4 : 1, E = NBW >= 4 ? 4 : NBW;
-    float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist + j0;
-    for (int e = threadIdx.x; e < M * Q; e += kWave * NBW) {
-        const int bin = e / Q, q = e % Q;
-#pragma unroll
-        for (int i = 0; i < E; i++)
-            if (j0 + E * q + i < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + E * q + i] = l_buf[E * q + i][bin];
+    // Xt[s][bin][xt_hist + j0 .. + NBW), inside every segment of 16 blocks in mfma_xt_pos order: thread -> (bin, position p of the
+    // workgroup's blocks); consecutive threads write consecutive positions (whole 128-byte lines for NBW = 16)
+    float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist;
+    for (int e = threadIdx.x; e < M * NBW; e += kWave * NBW) {
+        const int bin = e / NBW, p = e % NBW;
+        if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: position j0 + p takes block mfma_xt_pos(j0 + p)
+            const int t = mfma_xt_pos(j0 + p);
+            if (t < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + j0 + p] = l_buf[t - j0][bin];
+        } else {                                       // part of a segment: block j0 + p goes to its (scattered) position
+            if (j0 + p < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + mfma_xt_pos(j0 + p)] = l_buf[p][bin];
+        }
     }
 }
 
-// 8-byte buffer load: per-lane byte offset in a VGPR, row step in an SGPR, k group in the immediate; out of range reads 0
+// buffer loads: per-lane byte offset in a VGPR, row step in an SGPR, a constant in the immediate; everything the kernel addresses
+// exists in the padded layouts
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 template <int IMM>
 __device__ __forceinline__ float2 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff + IMM, 0);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <int IMM>
+__device__ __forceinline__ void buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 &lo, float2 &hi)
+{
+    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + IMM, 0);
+    lo = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    hi = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 // one component of the X operand moves one segment along: lane (n, kq) takes lane (n - 1, kq)'s value, lanes n = 0 keep `fresh`
@@ -152,73 +170,92 @@ __device__ __forceinline__ float shift_in(float fresh, float window)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fresh), __float_as_int(window), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
 }
 
+// every lane fetches the value lane `byte_addr / 4` holds (the LDS crossbar: no memory, no vector-ALU slot)
+__device__ __forceinline__ float2 from_lane(int byte_addr, float2 v)
+{
+    return make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v.y))));
+}
+
 // The chunks [jb, je) of one wave: its bin of one tile.  PACKED = bin 0 (DC and Nyquist: two real products).
-//   x operand of chunk j, k group g, lane (n, kq):  Xt[xt_hist + 256 tile + 16 (n - j) + 4 g + kq]
-//   h operand                       lane (i, kq):  Ht[16 + 16 j + i - 4 g - kq]
+//   x operand of chunk j, k group g, lane (n, kq):  block 256 tile + 16 (n - j) + 4 g + kq = Xt element x_elem0 + 16 (n - j) + 4 kq + g
+//   h operand                       lane (i, kq):  tap 16 j + i - 4 g - kq = Ht element 16 + that
+// What a chunk fetches is what is NEW, once per wave, and the lanes share it among themselves -- the texture path (one per CU, 64 bytes
+// a clock) is the resource sixteen independent waves run out of first: with every lane loading its own operands (8 loads of 512
+// bytes per chunk, most of them the same few addresses) the kernel took 37 us at configs[1], with a window re-loaded from the L1
+// every chunk 44 us, against 30 us with no loads at all (tools/mfma_stamps.hip, profiles/r04_mfma_stamps.txt):
+//   * taps: the 31 a chunk touches (16 j - 15 .. 16 j + 15) are ONE 8-byte load by lanes 0 .. 31; lane (i, kq) then takes tap
+//     i - kq - 4 g + 15 from that lane through ds_bpermute, four times (g) -- lane addresses that never change;
+//   * blocks: operand lane (n, kq) of chunk j + 1 holds what lane (n - 1, kq) held for chunk j, so a DPP row shift moves the window
+//     along and only the lanes n = 0 load: four lanes, 32 contiguous bytes each (mfma_xt_pos keeps a lane's four k groups together).
+// Two register sets swap roles every chunk (the loop is unrolled by two, nothing is copied): while one is multiplied, the other
+// receives the next chunk's taps and new blocks, issued one chunk of MFMAs before their use.
 template <bool PACKED>
 __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rh, int lane, int x_elem0, int jb, int je,
                                                v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i)
 {
     const int n = lane % kMfmaSeg, kq = lane / kMfmaSeg;
-    const unsigned vx_win = (unsigned) (kMfmaSeg * n + kq) * 8u, vx_new = (unsigned) kq * 8u, vh = (unsigned) (n - kq + 3) * 8u;
-    // scalar byte offsets: the window of chunk jb, the new row of chunk j (element x_elem0 - 16 j), the taps of chunk j
+    const unsigned vx = (unsigned) (kMfmaSeg * n + 4 * kq) * 8u;           // the lane's four k groups in the window's first chunk
+    const unsigned vx_new = (unsigned) (4 * kq) * 8u;                      // ... in a chunk's new segment (lanes n = 0)
+    const unsigned vh = (unsigned) (min(lane, 30) + 1) * 8u;               // lane l < 31 loads tap 16 j - 15 + l (Ht element 16 j + 1 + l)
+    int from[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) from[g] = (15 + n - kq - 4 * g) * 4;       // whose tap this lane multiplies with in k group g
+    // scalar byte offsets of chunk j: its window starts 16 j blocks before the tile, its taps at 16 j
     auto sx = [&](int j) { return (unsigned) (x_elem0 - kMfmaSeg * j) * 8u; };
     auto sh = [&](int j) { return (unsigned) (kMfmaSeg * j) * 8u; };
-    // Two register sets that swap roles every chunk (the loop is unrolled by two, so nothing is ever copied): while set A is
-    // multiplied, set B holds the next chunk's taps and -- in its lanes n = 0 -- the next chunk's new row of blocks; the DPP shift
-    // then completes B's window from A's in place, and A, now free, receives the loads of the chunk after that.  A load is issued
-    // one chunk of MFMAs (512 cycles alone, ~2000 with the SIMD's other waves) before its first use.
-    float2 xa[4], ha[4], xb[4], hb[4];
-    auto load_h = [&](float2 (&h)[4], int j) {
-        h[0] = buf_ld8<(13 - 0) * 8>(rh, vh, sh(j)); h[1] = buf_ld8<(13 - 4) * 8>(rh, vh, sh(j));
-        h[2] = buf_ld8<(13 - 8) * 8>(rh, vh, sh(j)); h[3] = buf_ld8<(13 - 12) * 8>(rh, vh, sh(j));
+    struct Set { float2 x[4], h[4], taps; };
+    Set A, B;
+    auto load_taps = [&](Set &s, int j) { if (lane < 32) s.taps = buf_ld8<0>(rh, vh, sh(j)); };
+    auto load_new = [&](Set &s, int j) {                                   // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
+        if (n == 0) { buf_ld16<0>(rx, vx_new, sx(j), s.x[0], s.x[1]); buf_ld16<16>(rx, vx_new, sx(j), s.x[2], s.x[3]); }
     };
-    auto load_x = [&](float2 (&x)[4], unsigned v, int j) {
-        x[0] = buf_ld8<0>(rx, v, sx(j)); x[1] = buf_ld8<32>(rx, v, sx(j)); x[2] = buf_ld8<64>(rx, v, sx(j)); x[3] = buf_ld8<96>(rx, v, sx(j));
+    auto spread_taps = [&](Set &s) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) s.h[g] = from_lane(from[g], s.taps);
     };
-    auto multiply = [&](const float2 (&x)[4], const float2 (&h)[4]) {
+    auto multiply = [&](const Set &s) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             if constexpr (PACKED) {
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].x, h[g].x, acc_r, 0, 0, 0);
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].y, h[g].y, acc_i, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].x, acc_r, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].y, acc_i, 0, 0, 0);
             } else {
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].x, h[g].x, acc_r, 0, 0, 0);
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].y, h[g].x, acc_i, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].y, h[g].y, acc_n, 0, 0, 0);      // subtracted at the end: no sign flip in the loop
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g].x, h[g].y, acc_i, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].x, acc_r, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].x, acc_i, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].y, acc_n, 0, 0, 0);      // subtracted at the end: no sign flip in the loop
+                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].y, acc_i, 0, 0, 0);
             }
         }
     };
-    // chunk j is multiplied out of (xc, hc); (xn, hn) -- loaded for chunk j + 1 -- becomes its window; then (xc, hc) is reloaded for chunk j + 2
-#ifndef IRB_MFMA_EXP
-#define IRB_MFMA_EXP 0                                 // diagnostic builds (tools/mfma_stamps.hip): 1 no window shift, 2 no loads in the loop -- timing only, wrong sums
-#endif
-    auto step = [&](int j, float2 (&xc)[4], float2 (&hc)[4], float2 (&xn)[4]) {
+    // chunk j is multiplied out of `cur`; `nxt` (its taps and new blocks loaded a chunk ago) becomes chunk j + 1's operands;
+    // `cur` is then reloaded for chunk j + 2
+    auto step = [&](int j, Set &cur, Set &nxt) {
         __builtin_amdgcn_sched_barrier(0);
-        multiply(xc, hc);
+        multiply(cur);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(IRB_MFMA_EXP & 1)) {
+        spread_taps(nxt);
 #pragma unroll
-            for (int g = 0; g < 4; g++) xn[g] = make_float2(shift_in(xn[g].x, xc[g].x), shift_in(xn[g].y, xc[g].y));
-        }
+        for (int g = 0; g < 4; g++) nxt.x[g] = make_float2(shift_in(nxt.x[g].x, cur.x[g].x), shift_in(nxt.x[g].y, cur.x[g].y));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(IRB_MFMA_EXP & 2)) {
-            load_x(xc, vx_new, j + 2);                 // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
-            load_h(hc, j + 2);
-        }
+        if constexpr (!(IRB_MFMA_EXP & 2)) { load_new(cur, j + 2); load_taps(cur, j + 2); }
     };
-    load_x(xa, vx_win, jb);
-    load_h(ha, jb);
-    load_x(xb, vx_new, jb + 1);
-    load_h(hb, jb + 1);
+    buf_ld16<0>(rx, vx, sx(jb), A.x[0], A.x[1]);                           // the whole window of the first chunk: every lane its own 32 bytes
+    buf_ld16<16>(rx, vx, sx(jb), A.x[2], A.x[3]);
+    A.taps = B.taps = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 4; g++) B.x[g] = make_float2(0.f, 0.f);
+    load_taps(A, jb);
+    load_new(B, jb + 1);
+    load_taps(B, jb + 1);
+    spread_taps(A);
     int j = jb;
 #pragma unroll 1
     for (; j + 1 < je; j += 2) {
-        step(j, xa, ha, xb);
-        step(j + 1, xb, hb, xa);
+        step(j, A, B);
+        step(j + 1, B, A);
     }
-    if (j < je) { __builtin_amdgcn_sched_barrier(0); multiply(xa, ha); }
+    if (j < je) { __builtin_amdgcn_sched_barrier(0); multiply(A); }
 }
 
 // grid = S * tile_count * splits * (M / 16); block = 1024.  Partial spectra: part[s][t - t_base][split][M], part_T blocks per

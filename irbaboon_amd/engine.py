@@ -90,6 +90,10 @@ class FdlEngine:
                                                  ir.ctypes.data_as(fp), first_partition))
         return y
 
+    def mac_kernel_name(self, n_blocks):
+        """which kernel a call of n_blocks blocks per stream multiplies with on this handle (irb_fdl_mac_kernel_name)"""
+        return _lib.lib().irb_fdl_mac_kernel_name(self._h, n_blocks).decode()
+
     def counters(self):
         v = [C.c_ulonglong() for _ in range(3)]
         check(_lib.lib().irb_fdl_get_counters(self._h, *[C.byref(x) for x in v]))

@@ -243,16 +243,24 @@ def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
     return full, min(by_work, res), tilesB, (splits_for(tilesB * units) if tilesB > 0 else 1)
 
 
+def mfma_xt_pos(t):
+    """position of block t inside its segment of 16 in Xt: [t % 4][t / 4 % 4] (a 4 x 4 transpose, its own inverse)"""
+    return (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3)
+
+
 def mfma_layouts(X, H, T, P):
     """The operands as the kernels that produce them lay them out for ONE bin: Xt = [history | the call's blocks | zeros up to whole
-    tiles] (k_xt_history / irb_fdl_reset, k_push_fft_batch_t), Ht = [16 zeros | taps | zeros] (k_rows_to_columns).
-    X: callable tau -> complex for tau in [-hist, T); H: the np taps in use (np <= P)."""
+    tiles], every segment of 16 in mfma_xt_pos order (k_rows_to_columns<PERM> / irb_fdl_reset, k_push_fft_batch_t), Ht = [16 zeros |
+    taps | zeros] (k_rows_to_columns).  X: callable tau -> complex for tau in [-hist, T); H: the np taps in use (np <= P)."""
     hist, taps = mfma_hist(P), mfma_taps(P)
     Tpad = (T + MFMA_TILE - 1) // MFMA_TILE * MFMA_TILE
-    xt = np.zeros(hist + Tpad, np.complex128)
+    lin = np.zeros(hist + Tpad, np.complex128)
     for tau in range(-hist, T):
-        xt[hist + tau] = X(tau)
-    xt[hist + T:] = 12345.0 + 6789.0j                  # what an earlier, longer call left behind: finite, must not matter
+        lin[hist + tau] = X(tau)
+    lin[hist + T:] = 12345.0 + 6789.0j                 # what an earlier, longer call left behind: finite, must not matter
+    xt = np.zeros_like(lin)
+    for e in range(len(lin)):
+        xt[mfma_xt_pos(e)] = lin[e]                    # (hist is a multiple of 16: segments of the call and of the buffer coincide)
     ht = np.zeros(taps, np.complex128)
     ht[16:16 + len(H)] = H
     return xt, ht, hist
@@ -260,27 +268,27 @@ def mfma_layouts(X, H, T, P):
 
 def mfma_wave(xt, ht, hist, tile, jb, je):
     """mfma_chunk_run for one wave (one bin of one tile, chunks [jb, je)): byte offsets of the buffer loads (per-lane voffset, scalar
-    offset, immediate), the two register sets that swap roles, the DPP row shift that moves the X window along, the MFMA's operand
-    and result maps.  Returns O[n][i] (16 x 16)."""
+    offset, immediate; 16-byte loads for X, 8-byte loads for H), the two register sets that swap roles, the MFMA's operand and
+    result maps.  Returns O[n][i] (16 x 16)."""
     lanes = [(l % 16, l // 16) for l in range(64)]                 # (n or i, kq)
     x_elem0 = hist + MFMA_TILE * tile
-    ld = lambda buf, byte: buf[byte // 8] if 0 <= byte // 8 < len(buf) else 0.0   # (nothing the kernel addresses is out of range: asserted below)
     sx = lambda j: (x_elem0 - 16 * j) * 8
     sh = lambda j: 16 * j * 8
 
-    def load_x(vx, j):
-        for g in range(4):
-            for n, kq in lanes:
-                assert 0 <= (vx(n, kq) + sx(j) + 32 * g) // 8 < len(xt)
-        return [[ld(xt, vx(n, kq) + sx(j) + 32 * g) for n, kq in lanes] for g in range(4)]
+    def ld(buf, byte):
+        assert byte % 8 == 0 and 0 <= byte // 8 < len(buf)          # nothing the kernel addresses is out of range
+        return buf[byte // 8]
 
-    def load_h(j):
-        for g in range(4):
-            for i, kq in lanes:
-                assert 0 <= ((i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) // 8 < len(ht)
-        return [[ld(ht, (i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) for i, kq in lanes] for g in range(4)]
+    def load(j):
+        x = [[None] * 64 for _ in range(4)]
+        for l, (n, kq) in enumerate(lanes):
+            vx = (16 * n + 4 * kq) * 8
+            for half in range(2):                                   # buffer_load_dwordx4 at immediate 0 and 16: two complex values each
+                x[2 * half][l] = ld(xt, vx + sx(j) + 16 * half)
+                x[2 * half + 1][l] = ld(xt, vx + sx(j) + 16 * half + 8)
+        h = [[ld(ht, (i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) for i, kq in lanes] for g in range(4)]
+        return x, h
 
-    vx_win, vx_new = (lambda n, kq: (16 * n + kq) * 8), (lambda n, kq: kq * 8)
     acc = np.zeros((16, 16), np.complex128)
 
     def multiply(x, h):
@@ -290,15 +298,12 @@ def mfma_wave(xt, ht, hist, tile, jb, je):
                     if kq2 == kq:
                         acc[n, i] += x[g][l] * h[g][l2]
 
-    def shift_in(fresh, window):                                   # v_mov_b32_dpp row_shr:1, bound_ctrl off: lanes n = 0 keep `fresh`
-        return [[fresh[g][l] if n == 0 else window[g][l - 1] for l, (n, kq) in enumerate(lanes)] for g in range(4)]
-
-    xa, ha = load_x(vx_win, jb), load_h(jb)
-    xb, hb = load_x(vx_new, jb + 1), load_h(jb + 1)
+    xa, ha = load(jb)
+    xb, hb = load(jb + 1)
     j = jb
     while j + 1 < je:
-        multiply(xa, ha); xb = shift_in(xb, xa); xa, ha = load_x(vx_new, j + 2), load_h(j + 2)
-        multiply(xb, hb); xa = shift_in(xa, xb); xb, hb = load_x(vx_new, j + 3), load_h(j + 3)
+        multiply(xa, ha); xa, ha = load(j + 2)
+        multiply(xb, hb); xb, hb = load(j + 3)
         j += 2
     if j < je:
         multiply(xa, ha)

@@ -1066,7 +1066,9 @@ def test_bench_multi_gpu_code_path_rehearsal(n, inst):
     assert len(d["per_gpu"]["Msamples_per_s"]) == n and d["value"] > 0
     # value = all shards' samples over the slowest shard's event time; the wall clock around the same region is beside it
     assert abs(d["value"] - n * inst * 256 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
-    assert abs(d["ms_per_step"] - d["per_gpu"]["kernel_ms_max"]) < 1e-3 and d["ms_per_step_wall"] > 0
+    # value follows the host wall clock (the contract's clock); the slowest engine's own events are reported beside it and cannot exceed it
+    assert abs(d["ms_per_step_device_events"] - d["per_gpu"]["kernel_ms_max"]) < 1e-3 and d["ms_per_step"] >= 0.98 * d["ms_per_step_device_events"]
+    assert len(d["setup_s_per_device"]) == n
     assert d["environment"]["library"].endswith("libirbfdl.so") and d["environment"]["irb_env"].get("IRB_BENCH_SHARE_DEVICE") == "1"
 
 
