@@ -61,6 +61,7 @@ struct irb_fdl {
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
     int tiled_kernel = 1;                    // time-tiled MAC: 1 k_cmac_tiled_pk (16 outputs x 8 partitions per step), 0 round 2's k_cmac_tiled<N,8> (IRB_TILED_KERNEL: A/B, tests)
     int tileTT = 16;                         // outputs per time tile of that kernel
+    bool tile8_fused = true;                 // calls of <= 8 blocks with one workgroup per stream: one launch (k_tile8_fused; IRB_TILED_FUSED8=0: the three-launch form)
     int mfma_min_T = 512;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
     int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
@@ -154,6 +155,14 @@ int dev_alloc(irb_fdl *h, T **p, size_t n)
     case 32:   { constexpr int NN = 32;   __VA_ARGS__; } break;                   \
     case 64:   { constexpr int NN = 64;   __VA_ARGS__; } break;                   \
     case 128:  { constexpr int NN = 128;  __VA_ARGS__; } break;                   \
+    case 256:  { constexpr int NN = 256;  __VA_ARGS__; } break;                   \
+    case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break;                   \
+    case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break;                   \
+    default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
+    }
+
+#define FOR_N_T8(N_, ...)                                                  \
+    switch (N_) {                                                          \
     case 256:  { constexpr int NN = 256;  __VA_ARGS__; } break;                   \
     case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break;                   \
     case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break;                   \
@@ -264,38 +273,44 @@ bool use_mfma(const irb_fdl *h, int T)
 }
 
 // How a call of T blocks is multiplied there.  A workgroup = one 256-block tile x 16 bins x one range of Toeplitz chunks and there
-// is one workgroup per CU at a time, so the grid should be whole rounds of (at most) mfma_wgs workgroups: a call whose tiles do
-// not fill a whole number of rounds is multiplied in TWO launches -- the full rounds unsplit (region A of the partial spectra,
-// one row per block), then the remaining tiles with their partitions split over the idle CUs (region B, nqB rows per block).
+// is one workgroup per CU at a time, so a launch should be whole rounds of (at most) mfma_wgs workgroups: a run of tiles that
+// does not fill a whole number of rounds is multiplied in TWO launches -- the full rounds unsplit, then the remaining tiles with
+// their partitions split over the idle CUs -- each with its own region of the partial spectra (its own rows per block).
 // (configs[1] one-shot: 4125 blocks = 17 tiles x 16 bin groups = 272 workgroups on 256 CUs would take two rounds for 6 % more
 // work than one; as 16 + 1 tiles the second launch is 64 workgroups of a quarter of the partitions each.)
+// `cut` (a multiple of 256, or 0) makes two such runs: irb_convolve_periodic multiplies the first half of a signal while the
+// second half is still arriving, and sends the first half's result while the second is multiplied.
+struct MfmaLaunch { int tile_first, tile_count, splits; };
 struct MfmaPlan {
-    int tilesA = 0, splitsA = 1, tilesB = 0, splitsB = 1;
-    int t_split(int T) const { return tilesB > 0 ? tilesA * irb::kMfmaTile : T; }          // blocks below it: region A
-    size_t part_rows(int S, int T) const { return (size_t) S * ((size_t) t_split(T) * splitsA + (size_t) (T - t_split(T)) * splitsB); }
+    int n = 0;
+    MfmaLaunch l[4];
+    int t0(int i, int T) const { return i < n ? l[i].tile_first * irb::kMfmaTile : T; }      // first block of launch i's region
+    size_t region_rows(int i, int S, int T) const { return (size_t) S * (size_t) (t0(i + 1, T) - t0(i, T)) * l[i].splits; }
+    size_t part_rows(int S, int T) const { size_t r = 0; for (int i = 0; i < n; i++) r += region_rows(i, S, T); return r; }
+    int launches_before(int block) const { int k = 0; while (k < n && l[k].tile_first * irb::kMfmaTile < block) k++; return k; }
 };
 
-MfmaPlan mfma_plan(const irb_fdl *h, int T)
+MfmaPlan mfma_plan(const irb_fdl *h, int T, int cut = 0)
 {
     MfmaPlan p;
-    const int ntiles = (T + irb::kMfmaTile - 1) / irb::kMfmaTile;
     const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
     const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);           // every split keeps a few chunks
-    const long slots = (long) h->mfma_wgs * h->mfma_res;                                     // workgroups resident at once (64 VGPRs, 34 KiB of LDS: two per CU)
+    const long slots = (long) h->mfma_wgs * h->mfma_res;                                     // workgroups resident at once
     auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, slots / std::max<long>(1, wgs))); };
     const long per_round = h->mfma_wgs / units;                                              // tiles that give every CU one workgroup
-    const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
-    if (full == 0 || !h->mfma_two_launch) {
-        p.tilesA = ntiles;
-        p.splitsA = ntiles * units <= h->mfma_wgs ? splits_for(ntiles * units) : 1;
-        return p;
-    }
-    // whole rounds: every CU holds mfma_res workgroups of 1 / mfma_res of the partitions each (one's first loads, barrier and
-    // stores run under the other's MFMAs)
-    p.tilesA = full;
-    p.splitsA = std::min(by_work, h->mfma_res);
-    p.tilesB = ntiles - full;
-    if (p.tilesB > 0) p.splitsB = splits_for(p.tilesB * units);
+    auto run = [&](int first, int ntiles) {                                                  // tiles [first, first + ntiles)
+        if (ntiles <= 0) return;
+        const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
+        if (full == 0 || !h->mfma_two_launch) {
+            p.l[p.n++] = {first, ntiles, ntiles * units <= h->mfma_wgs ? splits_for(ntiles * units) : 1};
+            return;
+        }
+        p.l[p.n++] = {first, full, std::min(by_work, h->mfma_res)};
+        if (ntiles > full) p.l[p.n++] = {first + full, ntiles - full, splits_for((ntiles - full) * units)};
+    };
+    const int ntiles = (T + irb::kMfmaTile - 1) / irb::kMfmaTile, tcut = cut > 0 && cut < T ? cut / irb::kMfmaTile : 0;
+    run(0, tcut > 0 ? tcut : ntiles);
+    if (tcut > 0) run(tcut, ntiles - tcut);
     return p;
 }
 
@@ -306,7 +321,9 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
     a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len;
     a.tile_first = 0; a.tile_count = 1; a.t_base = 0; a.part_T = 1;
-    a.t_first = 0; a.t_count = 1; a.part2 = nullptr; a.t_split = 1; a.nq2 = 1;
+    a.t_first = 0; a.t_count = 1;
+    for (int r = 0; r < 5; r++) a.reg_t0[r] = r == 0 ? 0 : 1;
+    for (int r = 0; r < 4; r++) { a.reg_nq[r] = 1; a.reg_off[r] = 0; }
     a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.stream_info = h->d_stream_info;
@@ -385,14 +402,14 @@ struct TiledCall {
     MfmaPlan plan;
 };
 
-int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
+int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c, int cut = 0)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     a.T = T;
     a.splits = tiled_splits(h, T);
     a.nq = a.splits * stripes;
     a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
-    a.t_first = 0; a.t_count = T; a.t_split = T; a.part2 = nullptr; a.nq2 = 1; a.part_T = T; a.t_base = 0;
+    a.t_first = 0; a.t_count = T; a.part_T = T; a.t_base = 0;
     c->T = T;
     // one complex bin per lane, 16 outputs per tile: fewer bytes per FMA.  Pays when the rows come from HBM (working
     // set beyond the Infinity Cache) and the call is long enough; cache-resident calls are faster with k_cmac_tiled
@@ -400,16 +417,23 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
     c->one_bin = !c->mfma && h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
     if (c->mfma) {
-        c->plan = mfma_plan(h, T);
-        a.splits = c->plan.splitsA; a.nq = c->plan.splitsA;
-        a.t_split = c->plan.t_split(T);
-        a.nq2 = c->plan.splitsB;
-        a.part2 = h->d_part + (size_t) h->S * a.t_split * a.nq * h->M;
+        c->plan = mfma_plan(h, T, cut);
         if (c->plan.part_rows(h->S, T) > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
+        long off = 0;
+        for (int r = 0; r < 5; r++) a.reg_t0[r] = c->plan.t0(r, T);
+        for (int r = 0; r < c->plan.n; r++) {
+            a.reg_nq[r] = c->plan.l[r].splits;
+            a.reg_off[r] = off;
+            off += (long) c->plan.region_rows(r, h->S, T) * h->M;
+        }
     }
     else if (c->one_bin) a.nq = a.splits * stripes1;
     else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
-    if (!c->mfma && (size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
+    if (!c->mfma) {
+        if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
+        for (int r = 0; r < 5; r++) a.reg_t0[r] = r == 0 ? 0 : T;                            // one region: part[s][t][nq][M]
+        a.reg_nq[0] = a.nq; a.reg_off[0] = 0;
+    }
     c->tt = tile_outputs(h, T);
     c->ntiles = c->one_bin ? (T + 15) / 16 : (T + c->tt - 1) / c->tt;
     c->a = a;
@@ -441,23 +465,24 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
     return IRB_OK;
 }
 
-int tiled_mac(irb_fdl *h, const TiledCall &c)
+// (matrix-core calls: launches [first_launch, first_launch + n_launches) of the plan; every other kernel is one launch)
+int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launches = 4)
 {
     irb::StepArgs a = c.a;
-    const int T = c.T;
     const dim3 mac_grid(h->S * c.ntiles * a.splits), mac_block(irb::kThreads);
     // HBM-sized batches with a single time tile per stream read every row once: non-temporal like the fused kernel
     const bool nt1 = h->nt && c.ntiles == 1;
     h->n_launches++;
     if (c.mfma) {
         const int groups = h->M / irb::kMfmaBins;
-        a.tile_first = 0; a.tile_count = c.plan.tilesA; a.t_base = 0; a.part_T = a.t_split;
-        FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * c.plan.tilesA * c.plan.splitsA * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
-        if (c.plan.tilesB > 0) {
+        float2 *const part0 = a.part;
+        h->n_launches--;
+        for (int i = first_launch; i < std::min(c.plan.n, first_launch + n_launches); i++) {
+            const MfmaLaunch &l = c.plan.l[i];
             h->n_launches++;
-            a.tile_first = c.plan.tilesA; a.tile_count = c.plan.tilesB; a.t_base = a.t_split; a.part_T = T - a.t_split;
-            a.splits = c.plan.splitsB; a.nq = c.plan.splitsB; a.part = const_cast<float2 *>(a.part2);
-            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * c.plan.tilesB * c.plan.splitsB * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+            a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
+            a.t_base = a.reg_t0[i]; a.part_T = a.reg_t0[i + 1] - a.reg_t0[i]; a.part = part0 + a.reg_off[i];
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * l.tile_count * l.splits * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
         }
     }
     else if (c.one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
@@ -490,8 +515,24 @@ void tiled_end(irb_fdl *h, const TiledCall &c)
     h->t += c.T;
 }
 
+// calls of at most 8 blocks on batches whose streams get one workgroup each: push, multiply and inverse in ONE launch (k_tile8_fused)
+bool use_tile8_fused(const irb_fdl *h, int T)
+{
+    return h->tile8_fused && h->tiled_kernel != 0 && h->N >= 256 && h->N <= 1024 && tile_outputs(h, T) == 8 && tiled_splits(h, T) == 1 && !use_mfma(h, T);
+}
+
 int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
 {
+    if (use_tile8_fused(h, T)) {
+        a.T = T;
+        a.ovl_next = h->d_ovl + (size_t) (h->ovl_cur ^ 1) * h->S * h->B;
+        h->n_launches++;
+        if (h->nt) { FOR_N_T8(h->N, irb::k_tile8_fused<NN, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else       { FOR_N_T8(h->N, irb::k_tile8_fused<NN, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        HIP_TRY(hipGetLastError());
+        h->ovl_cur ^= 1;
+        return IRB_OK;
+    }
     TiledCall c;
     int rc = tiled_begin(h, a, T, &c);
     if (rc == IRB_OK) rc = tiled_push(h, c, 0, T);
@@ -763,6 +804,8 @@ struct OfflineEngineGuard {
     std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
     hipStream_t s_ir = nullptr;                        // the IR's upload and transforms run beside the audio's forward FFTs ...
     hipEvent_t ev_ir = nullptr;                        // ... and join the engine's stream before the multiply
+    hipStream_t s2 = nullptr;                          // the second half of a signal (duplex form: PCIe in and out at the same time)
+    hipEvent_t ev_half[3] = {nullptr, nullptr, nullptr};   // first half pushed / first half multiplied / second half done
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -774,6 +817,8 @@ struct OfflineEngineGuard {
         (void) hipSetDevice(eng->device);
         (void) irb_sync(eng);
         if (s_ir) { (void) hipStreamSynchronize(s_ir); (void) hipStreamDestroy(s_ir); s_ir = nullptr; }
+        if (s2) { (void) hipStreamSynchronize(s2); (void) hipStreamDestroy(s2); s2 = nullptr; }
+        for (auto &e : ev_half) if (e) { (void) hipEventDestroy(e); e = nullptr; }
         irb_fdl_destroy(eng);
         eng = nullptr;
         for (auto &e : ev) if (e) (void) hipEventDestroy(e);
@@ -864,6 +909,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
     if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
     h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
+    h->tile8_fused = env_int("IRB_TILED_FUSED8", 1) != 0;
     h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 512));
     h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
     h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
@@ -901,7 +947,8 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
             size_t rows = (size_t) h->S * std::max(h->splits, 1);
             for (int T = 2; T <= h->Tmax && !h->stepwise; T++) {
-                if (use_mfma(h, T)) rows = std::max(rows, mfma_plan(h, T).part_rows(h->S, T));
+                if (use_mfma(h, T)) rows = std::max({rows, mfma_plan(h, T).part_rows(h->S, T),
+                                                     mfma_plan(h, T, T / 2 / irb::kMfmaTile * irb::kMfmaTile).part_rows(h->S, T)});   // (without / with the one-shot pipeline's cut)
                 else rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
             }
             h->part_rows = rows;
@@ -1008,6 +1055,7 @@ const char *irb_fdl_mac_kernel_name(const irb_fdl *h, int n_blocks)
         if (h->splits > 1) return (h->flags & IRB_FDL_SPLIT_3LAUNCH) ? "k_cmac_partial" : "k_step_split";
         return (h->pair && h->N <= 2048) ? "k_step_fused_pair" : "k_step_fused";
     }
+    if (use_tile8_fused(h, T)) return "k_tile8_fused";
     if (use_mfma(h, T)) return "k_cmac_mfma";
     if (h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048) return "k_cmac_tiled1<16>";
     if (h->tiled_kernel == 0) return "k_cmac_tiled<8>";
@@ -1539,6 +1587,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_ir, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev_ir, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s2, hipStreamNonBlocking);
+        for (auto &eh : g_offline.ev_half) if (e == hipSuccess) e = hipEventCreate(&eh);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
@@ -1584,8 +1634,9 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             prof.register_ms = now_ms() - t_reg;
             prof.setup_ms = t_reg - t_begin;
             const bool device_times = g_offline_profile_events;
-            float dev_ms[3] = {0, 0, 0};
-            int pieces = 0;
+            float dev_ms[4] = {0, 0, 0, 0};
+            int pieces = 0, mac_launches = 1;
+            bool duplexed = false;
             for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
                 const int T = (int) std::min<long>(Tneed, steps - p0);
                 irb::StepArgs a = step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride);
@@ -1593,22 +1644,58 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 a.in_len = std::max<long>(0, (long) La - p0 * B);           // blocks past the audio's end are the flush: zeros
                 a.out_len = std::max<long>(0, lim - p0 * B);                 // nothing is written past the samples this call produces
                 TiledCall call;
-                rc = tiled_begin(h, a, T, &call);
+                // duplex form (one piece of >= 4 tiles on the matrix cores): the signal in two halves, the second on a stream of its
+                // own -- half 2 arrives (PCIe in) while half 1 is multiplied, half 1's result leaves (PCIe out) while half 2 is multiplied
+                const bool duplex = use_mfma(h, T) && T >= 4 * irb::kMfmaTile && env_int("IRB_OFFLINE_DUPLEX", 1) != 0;
+                const int cut = duplex ? T / 2 / irb::kMfmaTile * irb::kMfmaTile : 0;
+                rc = tiled_begin(h, a, T, &call, cut);
                 if (rc != IRB_OK) break;
+                mac_launches = call.mfma ? call.plan.n : 1;
                 if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
-                rc = tiled_push(h, call, 0, T);
-                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
-                if (rc == IRB_OK) rc = join_ir();
-                if (rc == IRB_OK) rc = tiled_mac(h, call);
-                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
-                if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
+                if (!duplex) {
+                    rc = tiled_push(h, call, 0, T);
+                    if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
+                    if (rc == IRB_OK) rc = join_ir();
+                    if (rc == IRB_OK) rc = tiled_mac(h, call);
+                    if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
+                    if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
+                } else {
+                    hipStream_t s1 = h->stream;
+                    const int nA = call.plan.launches_before(cut);
+                    auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == IRB_OK) rc = fail(IRB_ERR_HIP, "duplex pipeline: %s", hipGetErrorString(e)); };
+                    rc = tiled_push(h, call, 0, cut);                                                  // s1: half 1 in
+                    ck(hipEventRecord(g.ev_half[0], s1));
+                    h->stream = g.s2;                                                                  // s2: half 2 in, behind half 1 (one PCIe direction)
+                    ck(hipStreamWaitEvent(g.s2, g.ev_half[0], 0));
+                    if (rc == IRB_OK) rc = tiled_push(h, call, cut, T - cut);
+                    if (device_times) ck(hipEventRecord(g.ev[1], g.s2));
+                    h->stream = s1;                                                                    // s1: multiply half 1, send its result
+                    if (rc == IRB_OK) rc = join_ir();
+                    if (rc == IRB_OK) rc = tiled_mac(h, call, 0, nA);
+                    ck(hipEventRecord(g.ev_half[1], s1));
+                    if (device_times) ck(hipEventRecord(g.ev[2], s1));
+                    if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, cut);
+                    h->stream = g.s2;                                                                  // s2: multiply half 2 (its history: half 1's blocks, pushed), send its result
+                    ck(hipStreamWaitEvent(g.s2, g.ev_ir, 0));
+                    if (rc == IRB_OK) rc = tiled_mac(h, call, nA, 4);
+                    ck(hipStreamWaitEvent(g.s2, g.ev_half[1], 0));                                     // (its first block adds the tail of half 1's last)
+                    if (rc == IRB_OK) rc = tiled_ifft(h, call, cut, T - cut);
+                    ck(hipEventRecord(g.ev_half[2], g.s2));
+                    h->stream = s1;
+                    ck(hipStreamWaitEvent(s1, g.ev_half[2], 0));                                       // everything of the call is now behind s1
+                    duplexed = true;
+                }
                 if (rc != IRB_OK) break;
                 tiled_end(h, call);
                 if (device_times) {
                     (void) hipEventRecord(g.ev[3], h->stream);
                     if (hipEventSynchronize(g.ev[3]) == hipSuccess) {
                         float ms = 0;
-                        for (int k = 0; k < 3; k++) if (hipEventElapsedTime(&ms, g.ev[k], g.ev[k + 1]) == hipSuccess) dev_ms[k] += ms;
+                        // duplex: [0] start -> half 2 in, [2] half 1 multiplied -> end (the phases overlap); else in / multiply / out
+                        if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;
+                        if (!duplex && hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;
+                        if (hipEventElapsedTime(&ms, g.ev[2], g.ev[3]) == hipSuccess) dev_ms[2] += ms;
+                        if (hipEventElapsedTime(&ms, g.ev[0], g.ev[3]) == hipSuccess) dev_ms[3] += ms;
                     }
                 }
             }
@@ -1622,12 +1709,13 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             if (rc != IRB_OK) return rc;
             prof.total_ms = now_ms() - t_begin;
             prof.direct = 1;
-            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
+            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times && !duplexed ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
+            prof.device_ms = device_times ? dev_ms[3] : -1.0;
+            prof.duplex = duplexed ? 1 : 0;
             prof.chunks = pieces; prof.blocks_per_chunk = Tneed; prof.pieces = pieces; prof.steps = (int) steps;
             prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
             {
-                const MfmaPlan pl = mfma_plan(h, (int) std::min<long>(Tneed, steps));
-                prof.mac_launches = prof.mac_on_matrix_cores ? (pl.tilesB > 0 ? 2 : 1) : 1;
+                prof.mac_launches = prof.mac_on_matrix_cores ? mac_launches : 1;
             }
             g.prof = prof; g.have_prof = true;
             return IRB_OK;
@@ -1729,11 +1817,11 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1];
     prof.wait_ms = wait_ms[0]; prof.wait_helper_ms = wait_ms[1];
     prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;   // (staged: the multiply is inside fft_in_ms)
+    prof.device_ms = device_times ? dev_ms[0] + dev_ms[1] : -1.0;
     prof.chunks = nio_total; prof.blocks_per_chunk = io; prof.pieces = pieces; prof.steps = (int) steps;
     prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
     {
-        const MfmaPlan pl = mfma_plan(h, Tneed);
-        prof.mac_launches = prof.mac_on_matrix_cores ? (pl.tilesB > 0 ? 2 : 1) : 1;
+        prof.mac_launches = prof.mac_on_matrix_cores ? mfma_plan(h, Tneed).n : 1;
     }
     g.prof = prof; g.have_prof = true;
     return rc;

@@ -73,9 +73,12 @@ struct StepArgs {
     int           t_base, part_T;           // ... and where its partial spectra go: part[s][t - t_base][nq][M], part_T blocks per stream
     // batched FFT kernels: the blocks [t_first, t_first + t_count) of the call (irb_convolve_periodic moves a call's blocks in and out in chunks)
     int           t_first, t_count;
-    // k_ifft_ola_run: blocks from t_split on have their partial spectra in part2[s][t - t_split][nq2][M] (t_split = T: all in `part`)
-    const float2 *part2;
-    int           t_split, nq2;
+    // k_ifft_ola_run: where the partial spectra of a block are.  A call's multiply may run as up to four launches (whole rounds of
+    // workgroups + remainder, twice when irb_convolve_periodic overlaps its two halves), each with its own region of `part`:
+    // region r holds blocks [reg_t0[r], reg_t0[r + 1]) as part + reg_off[r] + ((s * blocks of the region + block - reg_t0[r]) * reg_nq[r]) * M
+    int           reg_t0[5];    // (unused entries: the call's T)
+    int           reg_nq[4];
+    long          reg_off[4];   // in float2
     // ... and the samples that exist behind `in` / may be written behind `out`, per stream (irb_convolve_periodic lets these kernels read
     // the caller's audio and write the caller's result buffer in place: blocks past the end read as zeros / are cut off)
     long          in_len, out_len;

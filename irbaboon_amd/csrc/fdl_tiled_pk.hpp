@@ -182,6 +182,122 @@ __global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_tile8_fused: a call of T <= 8 blocks per stream for batches that give every stream ONE workgroup (HBM-sized batches of
+// short calls: a DAW host block of 2048 at B = 256) as a single launch -- k_push_fft_batch, k_cmac_tiled_pk<N, 8, 4> and
+// k_ifft_ola_run in one kernel, like k_step_fused for one block:
+//   A  the four waves transform the call's blocks (two each) into the FDL ring (fp/convolution.cpp:128-145); barrier
+//   B  the 8-output x 4-partition register tile over ALL partitions of the stream (tile_run, fp/convolution.cpp:171-202): every
+//      H row and every FDL row is read once for the eight outputs
+//   C  the stripes' sums meet in LDS: eight spectra
+//   D  the four waves invert them (two each, :206) and add the overlaps (:209-213): out[j] = y_j[0:B] + y_(j-1)[B:2B], the first from
+//      the overlap the previous call saved, the last one's second half saved for the next
+// Nothing but the FDL rows themselves goes through HBM twice: the three-launch form wrote the eight new spectra and eight partial
+// spectra per stream, flushed them at two kernel boundaries and read them back (profiles/r04_tiled8_pmc.txt: 18 + 24 us of
+// 572 and 67 MB of 3.3 GB at 2048 streams).  grid = S, block = 256; 256 <= N <= 1024.
+// ---------------------------------------------------------------------------------------------
+template <int N, bool NT>
+__global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2, TT = 8, U = 4, WAVES = kThreads / kWave, PER = TT / WAVES;
+    constexpr int VPL = M > kWave ? M / kWave : 1;     // samples per lane of a half block (B <= M)
+    static_assert(G::CPT == 1 && N >= 256, "one column block per thread");
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[TT][M];
+    __shared__ float4 l_red[G::STRIPES > 1 ? G::STRIPES - 1 : 1][TT][G::LW];
+    const int s = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
+    const float scale = 1.0f / (float) N;
+    // ---- A: forward FFTs of blocks wave, wave + 4
+    TwiddleStage<N, kThreads> tws;
+    tws.load(a.tw);
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) wave_load_block<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, l_buf[j], lane);
+    }
+    tws.store(l_tw);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) {
+            wave_fft<M, false>(l_buf[j], l_tw, lane);
+            float2 *dst = a.X + ((size_t) s * a.R + (a.head + j) % a.R) * M;
+            wave_split_forward<M>(l_buf[j], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
+        }
+    }
+    __syncthreads();                                   // (drains the stores: the new rows are in the L2 before any wave of this workgroup loads them)
+    // ---- B: the register tile over the stream's partitions, stripes = partition sub-ranges of whole ring periods
+    const int col = threadIdx.x % G::LW;
+    const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
+    const int nG = (np + kTilePeriod - 1) / kTilePeriod;
+    const int sb = (int) ((long) nG * stripe / G::STRIPES) * kTilePeriod, se = (int) ((long) nG * (stripe + 1) / G::STRIPES) * kTilePeriod;
+    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
+    const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
+    v2f_t acc[TT][2];
+#pragma unroll
+    for (int j = 0; j < TT; j++) { acc[j][0] = v2f_t{0.f, 0.f}; acc[j][1] = v2f_t{0.f, 0.f}; }
+    if (sb < se) {
+        const bool wave_has_col0 = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(col) == 0 : true;
+        if (wave_has_col0) tile_run<N, TT, U, NT, true>(H4, X4, col, sb, se, 0, a.head, a.R, acc, col == 0);
+        else               tile_run<N, TT, U, NT, false>(H4, X4, col, sb, se, 0, a.head, a.R, acc, false);
+    }
+    // ---- C: stripes -> eight spectra in l_buf
+    if constexpr (G::STRIPES > 1) {
+        if (stripe > 0) {
+#pragma unroll
+            for (int j = 0; j < TT; j++) l_red[stripe - 1][j][col] = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+        }
+        __syncthreads();
+    }
+    if (stripe == 0) {
+#pragma unroll
+        for (int j = 0; j < TT; j++) {
+            float4 v = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+#pragma unroll
+            for (int t = 0; t < G::STRIPES - 1; t++) {
+                const float4 w = l_red[t][j][col];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            reinterpret_cast<float4 *>(l_buf[j])[col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- D: inverse FFTs, overlap-add
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) {
+            wave_split_inverse<M>(l_buf[j], l_tw, lane);
+            wave_fft<M, true>(l_buf[j], l_tw, lane);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) {
+            const float *y = reinterpret_cast<const float *>(l_buf[j]);
+            const float *yp = reinterpret_cast<const float *>(l_buf[j > 0 ? j - 1 : 0]);
+            const float *o = a.ovl + (size_t) s * a.B;           // block 0 adds the overlap the previous call saved (kept out of registers until here: the tile needs them all)
+            float *out = a.out + (long) s * a.out_stride + (long) j * a.B;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                const int n = lane + i * kWave;
+                if (n < a.B) out[n] = y[n] * scale + (j > 0 ? yp[a.B + n] * scale : o[n]);
+            }
+            if (j == a.T - 1) {
+                float *on = a.ovl_next + (size_t) s * a.B;
+                for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_ifft_ola_run: inverse FFT + overlap-add of the time-tiled path without the duplicate transform.
 // A workgroup owns NB consecutive output blocks of one stream and runs NB + 1 waves: wave w transforms block
 // jb - 1 + w (wave 0: the predecessor of the run, needed only for its tail; for jb = 0 it fetches the saved
@@ -217,8 +333,9 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
         for (int i = 0; i < VPL; i++) ov[i] = o[min(lane + i * kWave, a.B - 1)];
     }
     if (live) {
-        if (j >= a.t_split) wave_sum_rows<N>(a.part2 + ((size_t) s * (a.T - a.t_split) + (j - a.t_split)) * a.nq2 * M, a.nq2, buf, lane);
-        else                wave_sum_rows<N>(a.part + ((size_t) s * a.t_split + j) * a.nq * M, a.nq, buf, lane);
+        const int r = (j >= a.reg_t0[1]) + (j >= a.reg_t0[2]) + (j >= a.reg_t0[3]);          // the region of block j (wave-uniform)
+        const int nq = a.reg_nq[r];
+        wave_sum_rows<N>(a.part + a.reg_off[r] + ((size_t) s * (a.reg_t0[r + 1] - a.reg_t0[r]) + (j - a.reg_t0[r])) * nq * M, nq, buf, lane);
     }
     tws.store(l_tw);
     __syncthreads();

@@ -228,19 +228,32 @@ def mfma_taps(P):
     return MFMA_SEG * (mfma_chunks(P) + 3)
 
 
-def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
-    """fdl_engine.hip: mfma_plan -- (tilesA, splitsA, tilesB, splitsB): whole rounds of workgroups (res per CU, each 1 / res of the
-    partitions), then the remaining tiles with their partitions split over all resident slots; units = streams x bin groups =
-    workgroups per tile at one split"""
-    ntiles = (T + MFMA_TILE - 1) // MFMA_TILE
+def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1, cut=0):
+    """fdl_engine.hip: mfma_plan -- the launches (tile_first, tile_count, splits) of one call: whole rounds of workgroups (res per CU,
+    each 1 / res of the partitions), then the remaining tiles with their partitions split over all resident slots; with `cut` (a
+    multiple of 256) the same for the tiles below and from the cut.  units = streams x bin groups = workgroups per tile at one split"""
     by_work = max(1, mfma_chunks(P) // min_chunks)
     splits_for = lambda w: max(1, min(by_work, wgs * res // max(1, w)))
     per_round = wgs // units
-    full = ntiles // per_round * per_round if per_round > 0 else ntiles
-    if full == 0:
-        return ntiles, (splits_for(ntiles * units) if ntiles * units <= wgs else 1), 0, 1
-    tilesB = ntiles - full
-    return full, min(by_work, res), tilesB, (splits_for(tilesB * units) if tilesB > 0 else 1)
+    out = []
+
+    def run(first, ntiles):
+        if ntiles <= 0:
+            return
+        full = ntiles // per_round * per_round if per_round > 0 else ntiles
+        if full == 0:
+            out.append((first, ntiles, splits_for(ntiles * units) if ntiles * units <= wgs else 1))
+            return
+        out.append((first, full, min(by_work, res)))
+        if ntiles > full:
+            out.append((first + full, ntiles - full, splits_for((ntiles - full) * units)))
+
+    ntiles = (T + MFMA_TILE - 1) // MFMA_TILE
+    tcut = cut // MFMA_TILE if 0 < cut < T else 0
+    run(0, tcut if tcut > 0 else ntiles)
+    if tcut > 0:
+        run(tcut, ntiles - tcut)
+    return out
 
 
 def mfma_xt_pos(t):
@@ -268,8 +281,9 @@ def mfma_layouts(X, H, T, P):
 
 def mfma_wave(xt, ht, hist, tile, jb, je):
     """mfma_chunk_run for one wave (one bin of one tile, chunks [jb, je)): byte offsets of the buffer loads (per-lane voffset, scalar
-    offset, immediate; 16-byte loads for X, 8-byte loads for H), the two register sets that swap roles, the MFMA's operand and
-    result maps.  Returns O[n][i] (16 x 16)."""
+    offset, immediate), which lanes load (the taps: lanes 0 .. 31, one 8-byte load; a chunk's new segment of blocks: the four lanes
+    n = 0, two 16-byte loads), ds_bpermute handing the taps to the lanes that multiply with them, the DPP row shift that moves
+    the X window along, the two register sets that swap roles, the MFMA's operand and result maps.  Returns O[n][i] (16 x 16)."""
     lanes = [(l % 16, l // 16) for l in range(64)]                 # (n or i, kq)
     x_elem0 = hist + MFMA_TILE * tile
     sx = lambda j: (x_elem0 - 16 * j) * 8
@@ -279,49 +293,84 @@ def mfma_wave(xt, ht, hist, tile, jb, je):
         assert byte % 8 == 0 and 0 <= byte // 8 < len(buf)          # nothing the kernel addresses is out of range
         return buf[byte // 8]
 
-    def load(j):
-        x = [[None] * 64 for _ in range(4)]
+    def ld32(byte):                                                 # two buffer_load_dwordx4 at immediates 0 and 16: the lane's four k groups
+        return [ld(xt, byte + 8 * g) for g in range(4)]
+
+    class Set:
+        def __init__(self):
+            self.x = [[0.0] * 64 for _ in range(4)]
+            self.h = [[0.0] * 64 for _ in range(4)]
+            self.taps = [0.0] * 64
+
+    def load_taps(s, j):                                            # lanes 0 .. 31: tap 16 j - 15 + l at Ht element 16 j + 1 + min(l, 30)
+        for l in range(32):
+            s.taps[l] = ld(ht, (min(l, 30) + 1) * 8 + sh(j))
+
+    def load_new(s, j):                                             # lanes n = 0: their four k groups of the segment chunk j adds
         for l, (n, kq) in enumerate(lanes):
-            vx = (16 * n + 4 * kq) * 8
-            for half in range(2):                                   # buffer_load_dwordx4 at immediate 0 and 16: two complex values each
-                x[2 * half][l] = ld(xt, vx + sx(j) + 16 * half)
-                x[2 * half + 1][l] = ld(xt, vx + sx(j) + 16 * half + 8)
-        h = [[ld(ht, (i - kq + 3) * 8 + sh(j) + (13 - 4 * g) * 8) for i, kq in lanes] for g in range(4)]
-        return x, h
+            if n == 0:
+                v = ld32(4 * kq * 8 + sx(j))
+                for g in range(4):
+                    s.x[g][l] = v[g]
+
+    def spread_taps(s):                                             # ds_bpermute: lane (i, kq) takes the tap lane 15 + i - kq - 4 g holds
+        for g in range(4):
+            for l, (i, kq) in enumerate(lanes):
+                src = 15 + i - kq - 4 * g
+                assert 0 <= src <= 30
+                s.h[g][l] = s.taps[src]
+
+    def shift(nxt, cur):                                            # v_mov_b32_dpp row_shr:1, bound_ctrl off: lanes n = 0 keep what they loaded
+        for g in range(4):
+            nxt.x[g] = [nxt.x[g][l] if n == 0 else cur.x[g][l - 1] for l, (n, kq) in enumerate(lanes)]
 
     acc = np.zeros((16, 16), np.complex128)
 
-    def multiply(x, h):
+    def multiply(s):
         for g in range(4):
             for l, (n, kq) in enumerate(lanes):                     # A operand lane (row n, k = kq), B operand lane (k = kq, column i)
                 for l2, (i, kq2) in enumerate(lanes):
                     if kq2 == kq:
-                        acc[n, i] += x[g][l] * h[g][l2]
+                        acc[n, i] += s.x[g][l] * s.h[g][l2]
 
-    xa, ha = load(jb)
-    xb, hb = load(jb + 1)
+    def step(j, cur, nxt):
+        multiply(cur)
+        spread_taps(nxt)
+        shift(nxt, cur)
+        load_new(cur, j + 2)
+        load_taps(cur, j + 2)
+
+    A, B = Set(), Set()
+    for l, (n, kq) in enumerate(lanes):                             # the whole window of the first chunk: every lane its own 32 bytes
+        v = ld32((16 * n + 4 * kq) * 8 + sx(jb))
+        for g in range(4):
+            A.x[g][l] = v[g]
+    load_taps(A, jb)
+    load_new(B, jb + 1)
+    load_taps(B, jb + 1)
+    spread_taps(A)
     j = jb
     while j + 1 < je:
-        multiply(xa, ha); xa, ha = load(j + 2)
-        multiply(xb, hb); xb, hb = load(j + 3)
+        step(j, A, B)
+        step(j + 1, B, A)
         j += 2
     if j < je:
-        multiply(xa, ha)
+        multiply(A)
     return acc
 
 
-def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
-    """k_cmac_mfma + the two-launch plan + k_ifft_ola_run's sum over partial spectra, for ONE bin: returns Y[t], t < T (float64:
-    this checks indices, not rounding)."""
+def mfma_time_axis(X, H, T, P=None, units=16, wgs=256, cut=0):
+    """k_cmac_mfma + the launch plan with its partial-spectrum regions + k_ifft_ola_run's region look-up and sum over partial
+    spectra, for ONE bin: returns Y[t], t < T (float64: this checks indices, not rounding)."""
     np_ = len(H)
     P = np_ if P is None else P
     xt, ht, hist = mfma_layouts(X, H, T, P)
     J = mfma_chunks(np_)
-    tilesA, splitsA, tilesB, splitsB = mfma_plan(T, units, P, wgs)
-    t_split = tilesA * MFMA_TILE if tilesB > 0 else T
-    partA = np.zeros((t_split, splitsA), np.complex128)             # part[t][split]
-    partB = np.zeros((max(T - t_split, 0), splitsB), np.complex128)
-    for tile_first, tile_count, splits, part, t_base in ((0, tilesA, splitsA, partA, 0), (tilesA, tilesB, splitsB, partB, t_split)):
+    plan = mfma_plan(T, units, P, wgs, cut=cut)
+    assert 1 <= len(plan) <= 4
+    t0 = [l[0] * MFMA_TILE for l in plan] + [T] * (5 - len(plan))               # reg_t0
+    parts = [np.zeros((t0[r + 1] - t0[r], plan[r][2]), np.complex128) for r in range(len(plan))]
+    for r, (tile_first, tile_count, splits) in enumerate(plan):
         for tile in range(tile_first, tile_first + tile_count):
             for split in range(splits):
                 jb, je = J * split // splits, J * (split + 1) // splits
@@ -330,5 +379,9 @@ def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
                     for i in range(16):
                         t = MFMA_TILE * tile + 16 * n + i
                         if t < T:
-                            part[t - t_base, split] = O[n, i]
-    return np.concatenate([partA.sum(axis=1), partB.sum(axis=1)])
+                            parts[r][t - t0[r], split] = O[n, i]
+    out = np.zeros(T, np.complex128)
+    for t in range(T):
+        r = (t >= t0[1]) + (t >= t0[2]) + (t >= t0[3])              # k_ifft_ola_run's look-up
+        out[t] = parts[r][t - t0[r]].sum()
+    return out

@@ -911,22 +911,28 @@ def test_single_tile_calls_with_non_temporal_rows(monkeypatch, B, Lh, T):
     (the bench's 2048 x 8-blocks entry).  Both tiles, with and without the non-temporal variant forced, against the oracle and
     against each other and round 2's kernel."""
     I, C = 3, 1
-    x = _streams(I, C, T * B, 8500)
+    x = _streams(I, C, 3 * T * B, 8500)                 # three calls of T blocks: the FDL and the overlap carry over between them
     irs = [decaying_ir(8510 + i, Lh)[None] for i in range(I)]
-    outs = []
-    for nt, kern, tt8 in (("1", "1", "1"), ("0", "1", "1"), ("1", "1", "0"), ("1", "0", "1")):
+    outs, kernels = [], []
+    # (non-temporal rows, tiled kernel generation, 8-output tile, one-launch form k_tile8_fused)
+    for nt, kern, tt8, fused in (("1", "1", "1", "1"), ("0", "1", "1", "1"), ("1", "1", "1", "0"), ("0", "1", "1", "0"), ("1", "1", "0", "1"), ("1", "0", "1", "1")):
         monkeypatch.setenv("IRB_FUSED_NT", nt)
         monkeypatch.setenv("IRB_TILED_KERNEL", kern)
         monkeypatch.setenv("IRB_TILED_TT8", tt8)
+        monkeypatch.setenv("IRB_TILED_FUSED8", fused)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            kernels.append(eng.mac_kernel_name(T))
             for i in range(I):
                 eng.set_ir(i, irs[i])
             outs.append(eng.process(x))
+    # calls of <= 8 blocks run as ONE launch by default, as three launches with IRB_TILED_FUSED8=0; 12-block calls never fuse
+    assert kernels[0] == kernels[1] == ("k_tile8_fused" if T <= 8 else "k_cmac_tiled_pk<16,8>")
+    assert kernels[2] == ("k_cmac_tiled_pk<8,4>" if T <= 8 else "k_cmac_tiled_pk<16,8>") and kernels[5] == "k_cmac_tiled<8>"
     for y in outs[1:]:
         assert rel_rms(y, outs[0]) < 2e-6
     for i in range(I):
         ref, _ = oracle.convolve_periodic(x[i:i + 1], irs[i], B)
-        assert rel_rms(outs[0][i], ref[0, :T * B]) < RMS_TOL
+        assert rel_rms(outs[0][i], ref[0, :3 * T * B]) < RMS_TOL
 
 
 # ---- the kernels the bench numbers come from (VERDICT r1: they must be output-checked, not only timed) ----
