@@ -234,12 +234,9 @@ typedef struct irb_convolve_profile {
     double fft_in_ms;           /* device: forward FFTs of all blocks (direct: reading the caller's audio over PCIe; staged: also the
                                    host's packing it waits for, and the multiply)                           */
     double mac_ms;              /* device: the multiply-accumulate (direct form; -1 in the staged form)     */
-    double fft_out_ms;          /* device: inverse FFTs + overlap-add of all blocks, written to the caller's buffer / the staging
-                                   (duplex: from the end of the first half's multiply to the end of the call)  */
+    double fft_out_ms;          /* device: inverse FFTs + overlap-add of all blocks, written to the caller's buffer / the staging */
     double device_ms;           /* device: first forward-FFT launch -> last inverse-FFT launch done          */
     int direct;                 /* 1: the kernels read / wrote the caller's (registered) memory; 0: staged copies */
-    int duplex;                 /* 1: the signal went through in two halves on two queues (PCIe in and out at the same time): fft_in_ms =
-                                   start -> second half in, mac_ms = -1 (the multiplies overlap the transfers)  */
     int chunks, blocks_per_chunk, pieces, steps;   /* steps = floor(La/B) + P (+1 without the reference's dropped tail); pieces = multiplies */
     int helper_thread, engine_created, mac_on_matrix_cores, mac_launches;
 } irb_convolve_profile;

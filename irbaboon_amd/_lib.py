@@ -38,7 +38,7 @@ class FdlInfo(C.Structure):
 class ConvolveProfile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("total_ms", "setup_ms", "register_ms", "pack_ms", "unpack_ms", "unpack_helper_ms", "wait_ms", "wait_helper_ms",
                                           "stall_ms", "fft_in_ms", "mac_ms", "fft_out_ms", "device_ms")] + \
-               [(n, C.c_int) for n in ("direct", "duplex", "chunks", "blocks_per_chunk", "pieces", "steps", "helper_thread", "engine_created",
+               [(n, C.c_int) for n in ("direct", "chunks", "blocks_per_chunk", "pieces", "steps", "helper_thread", "engine_created",
                                        "mac_on_matrix_cores", "mac_launches")]
 
     def as_dict(self):

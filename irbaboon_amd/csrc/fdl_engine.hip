@@ -278,19 +278,18 @@ bool use_mfma(const irb_fdl *h, int T)
 // their partitions split over the idle CUs -- each with its own region of the partial spectra (its own rows per block).
 // (configs[1] one-shot: 4125 blocks = 17 tiles x 16 bin groups = 272 workgroups on 256 CUs would take two rounds for 6 % more
 // work than one; as 16 + 1 tiles the second launch is 64 workgroups of a quarter of the partitions each.)
-// `cut` (a multiple of 256, or 0) makes two such runs: irb_convolve_periodic multiplies the first half of a signal while the
-// second half is still arriving, and sends the first half's result while the second is multiplied.
+// (Tried and dropped, profiles/r04_oneshot.txt: the one-shot call's signal in two halves on two queues, so that the second half
+// arrives while the first is multiplied and sent back -- 0.304 ms against 0.291 at configs[1]: the halves' kernels share the CUs.)
 struct MfmaLaunch { int tile_first, tile_count, splits; };
 struct MfmaPlan {
     int n = 0;
-    MfmaLaunch l[4];
+    MfmaLaunch l[2];
     int t0(int i, int T) const { return i < n ? l[i].tile_first * irb::kMfmaTile : T; }      // first block of launch i's region
     size_t region_rows(int i, int S, int T) const { return (size_t) S * (size_t) (t0(i + 1, T) - t0(i, T)) * l[i].splits; }
     size_t part_rows(int S, int T) const { size_t r = 0; for (int i = 0; i < n; i++) r += region_rows(i, S, T); return r; }
-    int launches_before(int block) const { int k = 0; while (k < n && l[k].tile_first * irb::kMfmaTile < block) k++; return k; }
 };
 
-MfmaPlan mfma_plan(const irb_fdl *h, int T, int cut = 0)
+MfmaPlan mfma_plan(const irb_fdl *h, int T)
 {
     MfmaPlan p;
     const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
@@ -306,11 +305,11 @@ MfmaPlan mfma_plan(const irb_fdl *h, int T, int cut = 0)
             return;
         }
         p.l[p.n++] = {first, full, std::min(by_work, h->mfma_res)};
-        if (ntiles > full) p.l[p.n++] = {first + full, ntiles - full, splits_for((ntiles - full) * units)};
+        // (the remainder's workgroups are few and short: down to three chunks per split)
+        if (ntiles > full) p.l[p.n++] = {first + full, ntiles - full,
+                                          (int) std::max<long>(1, std::min<long>(std::max(1, irb::mfma_chunks(h->P) / 3), slots / std::max<long>(1, (ntiles - full) * units)))};
     };
-    const int ntiles = (T + irb::kMfmaTile - 1) / irb::kMfmaTile, tcut = cut > 0 && cut < T ? cut / irb::kMfmaTile : 0;
-    run(0, tcut > 0 ? tcut : ntiles);
-    if (tcut > 0) run(tcut, ntiles - tcut);
+    run(0, (T + irb::kMfmaTile - 1) / irb::kMfmaTile);
     return p;
 }
 
@@ -319,11 +318,11 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     irb::StepArgs a;
     a.H = h->d_H; a.X = h->d_X; a.ovl = h->d_ovl + (size_t) h->ovl_cur * h->S * h->B; a.tw = h->d_tw;
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
-    a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len;
+    a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len; a.hist_first = -1;
     a.tile_first = 0; a.tile_count = 1; a.t_base = 0; a.part_T = 1;
     a.t_first = 0; a.t_count = 1;
-    for (int r = 0; r < 5; r++) a.reg_t0[r] = r == 0 ? 0 : 1;
-    for (int r = 0; r < 4; r++) { a.reg_nq[r] = 1; a.reg_off[r] = 0; }
+    for (int r = 0; r < 3; r++) a.reg_t0[r] = r == 0 ? 0 : 1;
+    for (int r = 0; r < 2; r++) { a.reg_nq[r] = 1; a.reg_off[r] = 0; }
     a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.stream_info = h->d_stream_info;
@@ -402,7 +401,7 @@ struct TiledCall {
     MfmaPlan plan;
 };
 
-int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c, int cut = 0)
+int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     a.T = T;
@@ -417,10 +416,10 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c, int cut = 0)
     c->one_bin = !c->mfma && h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048;
     const int stripes1 = irb::kThreads / std::min(h->M, irb::kThreads);
     if (c->mfma) {
-        c->plan = mfma_plan(h, T, cut);
+        c->plan = mfma_plan(h, T);
         if (c->plan.part_rows(h->S, T) > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
         long off = 0;
-        for (int r = 0; r < 5; r++) a.reg_t0[r] = c->plan.t0(r, T);
+        for (int r = 0; r < 3; r++) a.reg_t0[r] = c->plan.t0(r, T);
         for (int r = 0; r < c->plan.n; r++) {
             a.reg_nq[r] = c->plan.l[r].splits;
             a.reg_off[r] = off;
@@ -431,21 +430,19 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c, int cut = 0)
     else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
     if (!c->mfma) {
         if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
-        for (int r = 0; r < 5; r++) a.reg_t0[r] = r == 0 ? 0 : T;                            // one region: part[s][t][nq][M]
+        for (int r = 0; r < 3; r++) a.reg_t0[r] = r == 0 ? 0 : T;                            // one region: part[s][t][nq][M]
         a.reg_nq[0] = a.nq; a.reg_off[0] = 0;
     }
     c->tt = tile_outputs(h, T);
     c->ntiles = c->one_bin ? (T + 15) / 16 : (T + c->tt - 1) / c->tt;
     c->a = a;
+    c->a.hist_first = -1;
     if (c->mfma && h->t > 0) {
-        // the call continues a stream: the blocks before its first one go from the ring into Xt's history columns
+        // the call continues a stream: the blocks before its first one go from the ring into Xt's history columns (extra workgroups
+        // of the first forward-FFT launch)
         int first = (int) ((h->t - h->xt_hist) % h->R);
         if (first < 0) first += h->R;
-        h->n_launches++;
-        const dim3 grid(h->xt_hist / 16, h->M >= 64 ? h->M / 64 : 1, h->S);
-        FOR_N(h->N, irb::k_rows_to_columns<NN / 2, true><<<grid, dim3(256), 0, h->stream>>>(h->d_X, (long) h->R * h->M, first, h->R, h->xt_hist,
-                                                                                       h->d_Xt, (long) h->M * h->xt_len, h->xt_len, 0, h->xt_hist));
-        HIP_TRY(hipGetLastError());
+        c->a.hist_first = first;
     }
     return IRB_OK;
 }
@@ -456,7 +453,9 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
     a.t_first = first; a.t_count = count;
     h->n_launches++;
     if (c.mfma) {
-        FOR_N(h->N, irb::k_push_fft_batch_t<NN><<<dim3(h->S * ((count + irb::PushTGeom<NN>::NBW - 1) / irb::PushTGeom<NN>::NBW)),
+        if (first != 0) a.hist_first = -1;                              // (the call's first launch carries the history)
+        const int hist_wgs = a.hist_first >= 0 ? h->S * (h->xt_hist / 16) * std::max(1, h->M / 64) : 0;
+        FOR_N(h->N, irb::k_push_fft_batch_t<NN><<<dim3(h->S * ((count + irb::PushTGeom<NN>::NBW - 1) / irb::PushTGeom<NN>::NBW) + hist_wgs),
                                                   dim3(irb::kWave * irb::PushTGeom<NN>::NBW), 0, h->stream>>>(a, h->S));
     } else {
         FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * count + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
@@ -466,7 +465,7 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
 }
 
 // (matrix-core calls: launches [first_launch, first_launch + n_launches) of the plan; every other kernel is one launch)
-int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launches = 4)
+int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launches = 2)
 {
     irb::StepArgs a = c.a;
     const dim3 mac_grid(h->S * c.ntiles * a.splits), mac_block(irb::kThreads);
@@ -804,8 +803,6 @@ struct OfflineEngineGuard {
     std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
     hipStream_t s_ir = nullptr;                        // the IR's upload and transforms run beside the audio's forward FFTs ...
     hipEvent_t ev_ir = nullptr;                        // ... and join the engine's stream before the multiply
-    hipStream_t s2 = nullptr;                          // the second half of a signal (duplex form: PCIe in and out at the same time)
-    hipEvent_t ev_half[3] = {nullptr, nullptr, nullptr};   // first half pushed / first half multiplied / second half done
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -817,8 +814,6 @@ struct OfflineEngineGuard {
         (void) hipSetDevice(eng->device);
         (void) irb_sync(eng);
         if (s_ir) { (void) hipStreamSynchronize(s_ir); (void) hipStreamDestroy(s_ir); s_ir = nullptr; }
-        if (s2) { (void) hipStreamSynchronize(s2); (void) hipStreamDestroy(s2); s2 = nullptr; }
-        for (auto &e : ev_half) if (e) { (void) hipEventDestroy(e); e = nullptr; }
         irb_fdl_destroy(eng);
         eng = nullptr;
         for (auto &e : ev) if (e) (void) hipEventDestroy(e);
@@ -947,8 +942,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
             size_t rows = (size_t) h->S * std::max(h->splits, 1);
             for (int T = 2; T <= h->Tmax && !h->stepwise; T++) {
-                if (use_mfma(h, T)) rows = std::max({rows, mfma_plan(h, T).part_rows(h->S, T),
-                                                     mfma_plan(h, T, T / 2 / irb::kMfmaTile * irb::kMfmaTile).part_rows(h->S, T)});   // (without / with the one-shot pipeline's cut)
+                if (use_mfma(h, T)) rows = std::max(rows, mfma_plan(h, T).part_rows(h->S, T));
                 else rows = std::max(rows, (size_t) h->S * T * tiled_splits(h, T) * stripes);
             }
             h->part_rows = rows;
@@ -1587,8 +1581,6 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_ir, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev_ir, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s2, hipStreamNonBlocking);
-        for (auto &eh : g_offline.ev_half) if (e == hipSuccess) e = hipEventCreate(&eh);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
@@ -1636,7 +1628,6 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             const bool device_times = g_offline_profile_events;
             float dev_ms[4] = {0, 0, 0, 0};
             int pieces = 0, mac_launches = 1;
-            bool duplexed = false;
             for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
                 const int T = (int) std::min<long>(Tneed, steps - p0);
                 irb::StepArgs a = step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride);
@@ -1644,56 +1635,24 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 a.in_len = std::max<long>(0, (long) La - p0 * B);           // blocks past the audio's end are the flush: zeros
                 a.out_len = std::max<long>(0, lim - p0 * B);                 // nothing is written past the samples this call produces
                 TiledCall call;
-                // duplex form (one piece of >= 4 tiles on the matrix cores): the signal in two halves, the second on a stream of its
-                // own -- half 2 arrives (PCIe in) while half 1 is multiplied, half 1's result leaves (PCIe out) while half 2 is multiplied
-                const bool duplex = use_mfma(h, T) && T >= 4 * irb::kMfmaTile && env_int("IRB_OFFLINE_DUPLEX", 1) != 0;
-                const int cut = duplex ? T / 2 / irb::kMfmaTile * irb::kMfmaTile : 0;
-                rc = tiled_begin(h, a, T, &call, cut);
+                rc = tiled_begin(h, a, T, &call);
                 if (rc != IRB_OK) break;
                 mac_launches = call.mfma ? call.plan.n : 1;
                 if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
-                if (!duplex) {
-                    rc = tiled_push(h, call, 0, T);
-                    if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
-                    if (rc == IRB_OK) rc = join_ir();
-                    if (rc == IRB_OK) rc = tiled_mac(h, call);
-                    if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
-                    if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
-                } else {
-                    hipStream_t s1 = h->stream;
-                    const int nA = call.plan.launches_before(cut);
-                    auto ck = [&](hipError_t e) { if (e != hipSuccess && rc == IRB_OK) rc = fail(IRB_ERR_HIP, "duplex pipeline: %s", hipGetErrorString(e)); };
-                    rc = tiled_push(h, call, 0, cut);                                                  // s1: half 1 in
-                    ck(hipEventRecord(g.ev_half[0], s1));
-                    h->stream = g.s2;                                                                  // s2: half 2 in, behind half 1 (one PCIe direction)
-                    ck(hipStreamWaitEvent(g.s2, g.ev_half[0], 0));
-                    if (rc == IRB_OK) rc = tiled_push(h, call, cut, T - cut);
-                    if (device_times) ck(hipEventRecord(g.ev[1], g.s2));
-                    h->stream = s1;                                                                    // s1: multiply half 1, send its result
-                    if (rc == IRB_OK) rc = join_ir();
-                    if (rc == IRB_OK) rc = tiled_mac(h, call, 0, nA);
-                    ck(hipEventRecord(g.ev_half[1], s1));
-                    if (device_times) ck(hipEventRecord(g.ev[2], s1));
-                    if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, cut);
-                    h->stream = g.s2;                                                                  // s2: multiply half 2 (its history: half 1's blocks, pushed), send its result
-                    ck(hipStreamWaitEvent(g.s2, g.ev_ir, 0));
-                    if (rc == IRB_OK) rc = tiled_mac(h, call, nA, 4);
-                    ck(hipStreamWaitEvent(g.s2, g.ev_half[1], 0));                                     // (its first block adds the tail of half 1's last)
-                    if (rc == IRB_OK) rc = tiled_ifft(h, call, cut, T - cut);
-                    ck(hipEventRecord(g.ev_half[2], g.s2));
-                    h->stream = s1;
-                    ck(hipStreamWaitEvent(s1, g.ev_half[2], 0));                                       // everything of the call is now behind s1
-                    duplexed = true;
-                }
+                rc = tiled_push(h, call, 0, T);
+                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
+                if (rc == IRB_OK) rc = join_ir();
+                if (rc == IRB_OK) rc = tiled_mac(h, call);
+                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
+                if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
                 if (rc != IRB_OK) break;
                 tiled_end(h, call);
                 if (device_times) {
                     (void) hipEventRecord(g.ev[3], h->stream);
                     if (hipEventSynchronize(g.ev[3]) == hipSuccess) {
                         float ms = 0;
-                        // duplex: [0] start -> half 2 in, [2] half 1 multiplied -> end (the phases overlap); else in / multiply / out
                         if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;
-                        if (!duplex && hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;
+                        if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;
                         if (hipEventElapsedTime(&ms, g.ev[2], g.ev[3]) == hipSuccess) dev_ms[2] += ms;
                         if (hipEventElapsedTime(&ms, g.ev[0], g.ev[3]) == hipSuccess) dev_ms[3] += ms;
                     }
@@ -1709,9 +1668,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             if (rc != IRB_OK) return rc;
             prof.total_ms = now_ms() - t_begin;
             prof.direct = 1;
-            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times && !duplexed ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
+            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
             prof.device_ms = device_times ? dev_ms[3] : -1.0;
-            prof.duplex = duplexed ? 1 : 0;
             prof.chunks = pieces; prof.blocks_per_chunk = Tneed; prof.pieces = pieces; prof.steps = (int) steps;
             prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
             {

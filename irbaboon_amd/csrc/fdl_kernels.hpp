@@ -69,16 +69,17 @@ struct StepArgs {
     float2       *Xt;           // [S][M][xt_len]: element xt_hist + t = block t of the call, [0, xt_hist) = the blocks before it
     const float2 *Ht;           // [n_sets][M][ht_len]: element 16 + m = tap m (zeros in front and behind)
     int           xt_len, xt_hist, ht_len;
+    int           hist_first;   // >= 0: k_push_fft_batch_t also rebuilds Xt's history columns from the ring, starting at this ring row
     int           tile_first, tile_count;   // the 256-block tiles this launch multiplies (a call may take two launches) ...
     int           t_base, part_T;           // ... and where its partial spectra go: part[s][t - t_base][nq][M], part_T blocks per stream
     // batched FFT kernels: the blocks [t_first, t_first + t_count) of the call (irb_convolve_periodic moves a call's blocks in and out in chunks)
     int           t_first, t_count;
-    // k_ifft_ola_run: where the partial spectra of a block are.  A call's multiply may run as up to four launches (whole rounds of
-    // workgroups + remainder, twice when irb_convolve_periodic overlaps its two halves), each with its own region of `part`:
-    // region r holds blocks [reg_t0[r], reg_t0[r + 1]) as part + reg_off[r] + ((s * blocks of the region + block - reg_t0[r]) * reg_nq[r]) * M
-    int           reg_t0[5];    // (unused entries: the call's T)
-    int           reg_nq[4];
-    long          reg_off[4];   // in float2
+    // k_ifft_ola_run: where the partial spectra of a block are.  A matrix-core call's multiply may run as two launches (whole rounds of
+    // workgroups, then the remaining tiles with more partition splits), each with its own region of `part`: region r holds blocks
+    // [reg_t0[r], reg_t0[r + 1]) as part + reg_off[r] + ((s * blocks of the region + block - reg_t0[r]) * reg_nq[r]) * M
+    int           reg_t0[3];    // (one region: {0, T, T})
+    int           reg_nq[2];
+    long          reg_off[2];   // in float2
     // ... and the samples that exist behind `in` / may be written behind `out`, per stream (irb_convolve_periodic lets these kernels read
     // the caller's audio and write the caller's result buffer in place: blocks past the end read as zeros / are cut off)
     long          in_len, out_len;

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restric
 // whose long calls multiply on the matrix cores: every spectrum is written twice -- into the FDL ring (what every other kernel
 // reads and what the next call's history is rebuilt from) and, through LDS, into Xt with time contiguous per bin.
 // A workgroup = NBW consecutive blocks of one stream, one wave each; Xt leaves in pieces of NBW * 8 bytes (whole 128-byte lines
-// for N <= 512).  grid = S * ceil(t_count / NBW); t_first is a multiple of NBW.
+// for N <= 512).  grid = S * ceil(t_count / NBW) (+ S * (xt_hist / 16) * max(1, M / 64) workgroups that rebuild Xt's history columns
+// when the call continues a stream); t_first is a multiple of NBW.
 // ---------------------------------------------------------------------------------------------
 template <int N> struct PushTGeom { static constexpr int NBW = N <= 512 ? 16 : N == 1024 ? 8 : N == 2048 ? 4 : 2; };
 
@@ -115,6 +116,26 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     __shared__ float2 l_buf[NBW][M + 1];               // (+1: the transposed read below walks the block index at a fixed bin)
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int groups = (a.t_count + NBW - 1) / NBW;
+    if ((int) blockIdx.x >= S * groups) {
+        // extra workgroups of a call that continues a stream (a.hist_first >= 0): the xt_hist blocks before the call's first one go
+        // from the FDL ring into Xt's history columns -- k_rows_to_columns<M, true>'s work without a launch of its own, 16 ring
+        // rows x 64 bins per workgroup through LDS
+        constexpr int BW = M < 64 ? M : 64, BY = M / BW;
+        float2 (*l_t)[BW + 1] = reinterpret_cast<float2 (*)[BW + 1]>(&l_buf[0][0]);
+        const int w = blockIdx.x - S * groups, r0 = (w % (a.xt_hist / 16)) * 16, b0 = ((w / (a.xt_hist / 16)) % BY) * BW, s = w / ((a.xt_hist / 16) * BY);
+        const float2 *src = a.X + (size_t) s * a.R * M;
+        float2 *dst = a.Xt + (size_t) s * M * a.xt_len;
+        for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
+            const int r = e / BW, b = e % BW;
+            l_t[r][b] = src[(size_t) ((a.hist_first + r0 + r) % a.R) * M + b0 + b];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
+            const int b = e / 16, q = e % 16;
+            dst[(size_t) (b0 + b) * a.xt_len + r0 + q] = l_t[mfma_xt_pos(q)][b];
+        }
+        return;
+    }
     const int s = blockIdx.x / groups, j0 = a.t_first + (blockIdx.x % groups) * NBW;
     const int j = j0 + wave;
     const bool live = j < a.t_first + a.t_count;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
         for (int i = 0; i < VPL; i++) ov[i] = o[min(lane + i * kWave, a.B - 1)];
     }
     if (live) {
-        const int r = (j >= a.reg_t0[1]) + (j >= a.reg_t0[2]) + (j >= a.reg_t0[3]);          // the region of block j (wave-uniform)
+        const int r = j >= a.reg_t0[1] ? 1 : 0;                                              // the region of block j (wave-uniform)
         const int nq = a.reg_nq[r];
         wave_sum_rows<N>(a.part + a.reg_off[r] + ((size_t) s * (a.reg_t0[r + 1] - a.reg_t0[r]) + (j - a.reg_t0[r])) * nq * M, nq, buf, lane);
     }

@@ -228,10 +228,10 @@ def mfma_taps(P):
     return MFMA_SEG * (mfma_chunks(P) + 3)
 
 
-def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1, cut=0):
+def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
     """fdl_engine.hip: mfma_plan -- the launches (tile_first, tile_count, splits) of one call: whole rounds of workgroups (res per CU,
-    each 1 / res of the partitions), then the remaining tiles with their partitions split over all resident slots; with `cut` (a
-    multiple of 256) the same for the tiles below and from the cut.  units = streams x bin groups = workgroups per tile at one split"""
+    each 1 / res of the partitions), then the remaining tiles with their partitions split over all resident slots.
+    units = streams x bin groups = workgroups per tile at one split"""
     by_work = max(1, mfma_chunks(P) // min_chunks)
     splits_for = lambda w: max(1, min(by_work, wgs * res // max(1, w)))
     per_round = wgs // units
@@ -245,14 +245,10 @@ def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1, cut=0):
             out.append((first, ntiles, splits_for(ntiles * units) if ntiles * units <= wgs else 1))
             return
         out.append((first, full, min(by_work, res)))
-        if ntiles > full:
-            out.append((first + full, ntiles - full, splits_for((ntiles - full) * units)))
+        if ntiles > full:                                            # the remainder's workgroups are few and short: down to three chunks per split
+            out.append((first + full, ntiles - full, max(1, min(max(1, mfma_chunks(P) // 3), wgs * res // max(1, (ntiles - full) * units)))))
 
-    ntiles = (T + MFMA_TILE - 1) // MFMA_TILE
-    tcut = cut // MFMA_TILE if 0 < cut < T else 0
-    run(0, tcut if tcut > 0 else ntiles)
-    if tcut > 0:
-        run(tcut, ntiles - tcut)
+    run(0, (T + MFMA_TILE - 1) // MFMA_TILE)
     return out
 
 
@@ -359,16 +355,16 @@ def mfma_wave(xt, ht, hist, tile, jb, je):
     return acc
 
 
-def mfma_time_axis(X, H, T, P=None, units=16, wgs=256, cut=0):
+def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
     """k_cmac_mfma + the launch plan with its partial-spectrum regions + k_ifft_ola_run's region look-up and sum over partial
     spectra, for ONE bin: returns Y[t], t < T (float64: this checks indices, not rounding)."""
     np_ = len(H)
     P = np_ if P is None else P
     xt, ht, hist = mfma_layouts(X, H, T, P)
     J = mfma_chunks(np_)
-    plan = mfma_plan(T, units, P, wgs, cut=cut)
-    assert 1 <= len(plan) <= 4
-    t0 = [l[0] * MFMA_TILE for l in plan] + [T] * (5 - len(plan))               # reg_t0
+    plan = mfma_plan(T, units, P, wgs)
+    assert 1 <= len(plan) <= 2
+    t0 = [l[0] * MFMA_TILE for l in plan] + [T] * (3 - len(plan))               # reg_t0
     parts = [np.zeros((t0[r + 1] - t0[r], plan[r][2]), np.complex128) for r in range(len(plan))]
     for r, (tile_first, tile_count, splits) in enumerate(plan):
         for tile in range(tile_first, tile_first + tile_count):
@@ -382,6 +378,6 @@ def mfma_time_axis(X, H, T, P=None, units=16, wgs=256, cut=0):
                             parts[r][t - t0[r], split] = O[n, i]
     out = np.zeros(T, np.complex128)
     for t in range(T):
-        r = (t >= t0[1]) + (t >= t0[2]) + (t >= t0[3])              # k_ifft_ola_run's look-up
+        r = 1 if t >= t0[1] else 0                                  # k_ifft_ola_run's look-up
         out[t] = parts[r][t - t0[r]].sum()
     return out

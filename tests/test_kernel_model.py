@@ -56,13 +56,13 @@ def test_fused_split_row_pairing(M1, M2, R):
     assert np.all(seen == 1)
 
 
-@pytest.mark.parametrize("np_,P,T,units,wgs,cut", [(1, 1, 5, 16, 256, 0), (15, 15, 40, 16, 256, 0), (16, 16, 256, 16, 256, 0), (17, 40, 300, 16, 256, 0),
-                                                   (150, 150, 257, 16, 256, 0), (375, 375, 70, 16, 256, 0), (160, 375, 33, 4, 256, 0),
-                                                   (100, 100, 600, 16, 32, 0), (33, 33, 1100, 8, 16, 0), (40, 40, 1100, 8, 16, 512), (20, 20, 700, 16, 32, 256)])
-def test_toeplitz_block_time_axis(np_, P, T, units, wgs, cut):
+@pytest.mark.parametrize("np_,P,T,units,wgs", [(1, 1, 5, 16, 256), (15, 15, 40, 16, 256), (16, 16, 256, 16, 256), (17, 40, 300, 16, 256),
+                                               (150, 150, 257, 16, 256), (375, 375, 70, 16, 256), (160, 375, 33, 4, 256),
+                                               (100, 100, 600, 16, 32), (33, 33, 1100, 8, 16)])
+def test_toeplitz_block_time_axis(np_, P, T, units, wgs):
     """fdl_mfma.hpp: one bin's time axis as sums of 16 x 16 Toeplitz-block products -- the transposed layouts (history, zero taps in front
     and behind, stale finite values beyond the call), tiles, partition splits, the two-launch plan with its two partial-spectrum
-    regions (with and without the one-shot pipeline's cut), the buffer loads' byte offsets, the register sets that swap roles and the MFMA operand /
+    regions, the buffer loads' byte offsets, the register sets that swap roles and the MFMA operand /
     result maps, restated in numpy -- equals the direct sum Y[t] = sum_m H[m] X[t - m] over the FDL history and the call's blocks.
     (wgs < 256 stands in for a smaller chip so that small cases reach the two-launch branch.)"""
     from kernel_model import mfma_chunks, mfma_hist, mfma_plan, mfma_time_axis
@@ -71,12 +71,11 @@ def test_toeplitz_block_time_axis(np_, P, T, units, wgs, cut):
     hist = mfma_hist(P)
     xs = rng.standard_normal(hist + T) + 1j * rng.standard_normal(hist + T)          # X[tau] at index tau + hist: history first
     X = lambda tau: xs[tau + hist]
-    got = mfma_time_axis(X, H, T, P, units, wgs, cut)
+    got = mfma_time_axis(X, H, T, P, units, wgs)
     ref = np.array([sum(H[m] * X(t - m) for m in range(np_)) for t in range(T)])
     assert np.abs(got - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
     J = mfma_chunks(np_)
     assert 16 * (J - 1) - 15 <= np_ - 1 < 16 * J            # the last chunk is needed, one more would multiply zeros only
     assert hist >= np_ - 1                                   # the history columns hold every block an output can depend on
-    plan = mfma_plan(T, units, P, wgs, cut=cut)
+    plan = mfma_plan(T, units, P, wgs)
     assert sum(l[1] for l in plan) == (T + 255) // 256 and all(a[0] + a[1] == b[0] for a, b in zip(plan, plan[1:]))     # the launches tile the call
-    assert cut == 0 or any(l[0] * 256 == cut for l in plan)                                                               # a launch starts at the cut
