@@ -94,6 +94,10 @@ void irb_lfft_destroy(irb_lfft *p);
  * zeros above the Nyquist bin are already there); a caller that stores into floats N+2 .. 2N-1 of d_spec itself must
  * clear them again before the next forward transform into it.  Forward transforms into any other buffer write all 2N floats. */
 int  irb_lfft_buffers(irb_lfft *p, float **d_time, float **d_spec);
+/* for a caller that has stored into floats N+2 .. 2N-1 of the plan's d_spec (through the pointer above): the next forward transform
+ * into d_spec of the plan's full batch writes all 2N floats of every item again and the short form resumes behind it
+ * (no reference counterpart: the reference's transform rewrites its whole work buffer every time, fp/tools.cpp:331-335) */
+int  irb_lfft_invalidate_spec(irb_lfft *p);
 /* performRealOnlyForwardTransform / performRealOnlyInverseTransform (fp/tools.cpp:335,363) on device buffers */
 int  irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int batch);   /* asynchronous */
 int  irb_lfft_inverse_device(irb_lfft *p, const float *d_spec, float *d_out, int batch);  /* asynchronous */

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("irb_lfft_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("irb_lfft_destroy", None, [C.c_void_p]),
     ("irb_lfft_buffers", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("irb_lfft_invalidate_spec", C.c_int, [C.c_void_p]),
     ("irb_lfft_forward_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("irb_lfft_inverse_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("irb_lfft_synchronize", C.c_int, [C.c_void_p]),

@@ -59,6 +59,7 @@ struct irb_lfft {
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_tabA = nullptr, *d_tabB = nullptr;
     float2 *d_w0 = nullptr, *d_w1 = nullptr;     // complex work buffers [max_batch][M]
     float *d_time = nullptr, *d_spec = nullptr;  // [max_batch][N] samples, [max_batch][2N] spectrum (one-shot API)
+    bool spec_refill = false;                    // irb_lfft_invalidate_spec: the next forward transform into d_spec restores the zeros and the flag
     bool spec_upper_zero = false;                // floats above the Nyquist bin of d_spec are zero (set at create, kept by every
                                                  // kernel of this library: they write bins 0..N/2 only): forward into d_spec skips the fill
     // smoothing (averagingFilter) workspace, created by the first smoothing call on this plan: log amplitudes and window
@@ -336,6 +337,7 @@ int irb_lfft_forward_device(irb_lfft *p, const float *d_in, float *d_spec, int b
     if (batch < 1 || batch > p->max_batch) return irb_set_error_(IRB_ERR_ARG, "batch out of range");
     HIP_TRY(hipSetDevice(p->device));
     const bool fill = !(d_spec == p->d_spec && p->spec_upper_zero);  // 4 MB of zeros per 2^20-point item unless they are known to be there
+    if (fill && d_spec == p->d_spec && p->spec_refill && batch == p->max_batch) { p->spec_upper_zero = true; p->spec_refill = false; }   // this call rewrites every float of the buffer
     if (fused_split(p, true)) {                                     // columns pass, then rows pass + split in one launch
         irb::LfftArgs a = args_of(p, batch);
         a.zero_fill = fill;
@@ -400,6 +402,14 @@ int irb_lfft_elapsed_ms(irb_lfft *p, float *ms)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventSynchronize(p->ev[1]));
     HIP_TRY(hipEventElapsedTime(ms, p->ev[0], p->ev[1]));
+    return IRB_OK;
+}
+
+int irb_lfft_invalidate_spec(irb_lfft *p)
+{
+    if (!p) return irb_set_error_(IRB_ERR_ARG, "null handle");
+    p->spec_upper_zero = false;                        // the next forward transform into the plan's spectrum buffer writes all 2N floats again ...
+    p->spec_refill = true;                             // ... and re-arms the short form behind it
     return IRB_OK;
 }
 

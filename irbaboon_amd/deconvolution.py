@@ -85,6 +85,10 @@ class LargeFft:
 
     __del__ = close
 
+    def invalidate_spec(self):
+        """after writing above the Nyquist bin of d_spec yourself: the next forward() restores the layout's zeros (irb_lfft_invalidate_spec)"""
+        check(_lib.lib().irb_lfft_invalidate_spec(self._h))
+
     def forward(self, batch=1):
         check(_lib.lib().irb_lfft_forward_device(self._h, self.d_time, self.d_spec, batch))
 

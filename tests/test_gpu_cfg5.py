@@ -179,6 +179,33 @@ def test_large_fft_tile_heights(monkeypatch, tile, fuse):
     ib.lib().irb_release_cached_plans()
 
 
+def test_large_fft_plan_spectrum_buffer_contract():
+    """irb_lfft_*: a forward transform INTO the plan's own spectrum buffer writes bins 0 .. N/2 only (the zeros the reference layout has
+    above the Nyquist bin, fp/tools.hpp:84-87, were put there once).  A caller that stores above the Nyquist bin through the
+    pointer irb_lfft_buffers hands out breaks that -- documented -- and irb_lfft_invalidate_spec re-arms the full write."""
+    n = 1 << 14
+    x = white_noise(77, n)
+    plan = ib.LargeFft(n, 1)
+    with ib.FdlEngine(1, 1, 16, 16) as io:                       # (only for its upload / download helpers: they take any device pointer)
+        io.upload(plan.d_time, x)
+        plan.forward()
+        plan.synchronize()
+        F = io.download(plan.d_spec, 2 * n)
+        ref = np.fft.rfft(x.astype(np.float64))
+        assert np.sqrt(np.mean(np.abs(_bins(F, n) - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 2e-6 and not F[n + 2:].any()
+        io.upload(plan.d_spec + 4 * (n + 2), np.full(n - 2, 7.0, np.float32))      # the caller dirties floats N+2 .. 2N-1
+        plan.forward()
+        plan.synchronize()
+        assert (io.download(plan.d_spec, 2 * n)[n + 2:] == 7.0).all()              # the documented contract: not rewritten by itself
+        plan.invalidate_spec()
+        for _ in range(2):                                                         # the next forward restores the zeros; the one after keeps them
+            plan.forward()
+            plan.synchronize()
+            F = io.download(plan.d_spec, 2 * n)
+            assert not F[n + 2:].any() and np.sqrt(np.mean(np.abs(_bins(F, n) - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 2e-6
+    plan.close()
+
+
 # ---- SURVEY section 8(f) ranks 3 and 4 ----------------------------------------------------------------
 import os  # noqa: E402
 

@@ -903,6 +903,32 @@ def test_packed_fma_tiled_kernel(monkeypatch, I, C, B, Lh, T):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
 
 
+@pytest.mark.parametrize("min_t", ["2", "0"], ids=["matrix_cores", "packed_fma"])
+def test_non_finite_sample_stays_inside_the_documented_window(monkeypatch, min_t):
+    """include/irb_fdl.h (irb_fdl_process): calls of several blocks multiply in tiles along the time axis whose zero padding meets
+    neighbouring blocks, so an Inf / NaN sample can reach output blocks a tile's width outside the np blocks it reaches in the
+    reference -- and no further.  One NaN in block 400 of 900 (np = 20 partitions): every output block more than 31 blocks
+    before it and more than np + 255 blocks after it is finite and equals the clean run's; the blocks the reference poisons
+    (400 .. 400 + np - 1) are poisoned here too."""
+    B, Lh, T, bad = 32, 20 * 32, 900, 400
+    P = Lh // B
+    x = white_noise(8700, T * B)[None].copy()
+    h = decaying_ir(8701, Lh)[None]
+    monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", min_t)
+    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=T) as eng:
+        eng.set_ir(0, h)
+        clean = eng.process(x)
+        eng.reset()
+        x[0, bad * B + 5] = np.nan
+        y = eng.process(x)[0].reshape(T, B)
+    clean = clean[0].reshape(T, B)
+    finite = np.isfinite(y).all(axis=1)
+    assert not finite[bad:bad + P].any()                                   # the reference's own reach
+    lo, hi = bad - 31, bad + P + 255
+    assert finite[:lo].all() and finite[hi + 1:].all()
+    assert np.array_equal(y[:lo], clean[:lo]) and np.array_equal(y[hi + 1:], clean[hi + 1:])
+
+
 @pytest.mark.parametrize("B,Lh", [(256, 9000), (128, 3000), (512, 9000)])
 @pytest.mark.parametrize("T", [3, 8, 12], ids=["T3_tile8", "T8_tile8", "T12_tile16"])
 def test_single_tile_calls_with_non_temporal_rows(monkeypatch, B, Lh, T):
