@@ -1562,7 +1562,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     irb_convolve_profile prof;
     std::memset(&prof, 0, sizeof prof);
     const int io = std::max(16, (env_int("IRB_OFFLINE_CHUNK", kOfflineChunk) + 15) / 16 * 16);   // multiple of the FFT kernels' blocks per workgroup
-    const int Tneed = (int) std::min<long>(steps, kOfflineMaxBlocks);
+    const int Tneed = (int) std::min<long>(steps, std::max(2, env_int("IRB_OFFLINE_MAX_BLOCKS", kOfflineMaxBlocks)));   // (override: tests run several pieces on small signals)
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     irb_fdl *h = g_offline.eng;

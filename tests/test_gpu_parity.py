@@ -123,6 +123,69 @@ def test_convolve_periodic_edge_cases():
     assert rel_rms(y, direct_f64(x, h)) < RMS_TOL
 
 
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["direct", "staged"])
+def test_convolve_periodic_in_several_pieces(monkeypatch, direct):
+    """irb_convolve_periodic on signals longer than one multiply takes: the FDL (ring, overlap, the matrix-core path's history
+    columns) carries from piece to piece.  25 062 steps at B = 16 are two pieces of the default 16 384; IRB_OFFLINE_MAX_BLOCKS = 700 /
+    5 makes it many (on the matrix cores / on the packed-FMA tile).  Both forms of the call: the kernels working in the caller's
+    registered memory, and pinned staging."""
+    monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+    B, Lh, La = 16, 1000, 400000
+    x, h = white_noise(7700, La)[None], decaying_ir(7701, Lh)[None]
+    ref = scipy.signal.fftconvolve(x[0].astype(np.float64), h[0].astype(np.float64))
+    for max_blocks in (None, "700", "5"):
+        if max_blocks:
+            monkeypatch.setenv("IRB_OFFLINE_MAX_BLOCKS", max_blocks)
+        n = La if max_blocks != "5" else 2000                       # (five-block pieces: a short signal is enough)
+        y = convolvePeriodic(x[:, :n], h, B, keep_reference_tail=False)
+        r = ref if n == La else scipy.signal.fftconvolve(x[0, :n].astype(np.float64), h[0].astype(np.float64))
+        assert y.shape == (1, n + Lh - 1) and rel_rms(y[0], r) < RMS_TOL
+        irbaboon_amd_release()
+
+
+def irbaboon_amd_release():
+    import irbaboon_amd
+    irbaboon_amd.lib().irb_release_cached_plans()
+
+
+def test_convolve_periodic_on_awkward_caller_memory():
+    """The direct form registers the caller's pages: channels in separate allocations, pointers that are not even 16-byte aligned,
+    audio and result living in ONE allocation (shared pages: one registration), and a result buffer that is pinned memory already
+    (registration refused: the staged form takes over) -- all through the C ABI with hand-made pointer arrays."""
+    import ctypes
+    lib = _lib.lib()
+    B, Lh, La = 256, 5000, 60000
+    h = np.stack([decaying_ir(7800, Lh), decaying_ir(7801, Lh)])
+    big = np.zeros(4 * (La + Lh) + 64, np.float32)                   # audio L | result L | audio R | result R, odd offsets, one allocation
+    xs = [white_noise(7810 + c, La) for c in range(2)]
+    a_off, o_off = [3, 2 * (La + Lh) + 5], [La + 7, 3 * (La + Lh) + 9]
+    for c in range(2):
+        big[a_off[c]:a_off[c] + La] = xs[c]
+    fpp = lambda arrs: (_lib.fp * len(arrs))(*[a.ctypes.data_as(_lib.fp) for a in arrs])
+    audio = [big[a_off[c]:a_off[c] + La] for c in range(2)]
+    out = [big[o_off[c]:o_off[c] + La + Lh - 1] for c in range(2)]
+    hp = _lib.planar_ptrs(h)
+    prof = _lib.ConvolveProfile()
+    _lib.check(lib.irb_convolve_periodic(0, fpp(audio), 2, La, hp, 2, Lh, B, 0, fpp(out)))
+    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
+    assert prof.direct == 1
+    for c in range(2):
+        assert rel_rms(out[c], scipy.signal.fftconvolve(xs[c].astype(np.float64), h[c].astype(np.float64))) < RMS_TOL
+        assert np.array_equal(big[a_off[c]:a_off[c] + La], xs[c])    # the audio next to it is untouched
+    # separate allocations per channel
+    sep_out = [np.empty(La + Lh - 1, np.float32) for _ in range(2)]
+    _lib.check(lib.irb_convolve_periodic(0, fpp(xs), 2, La, hp, 2, Lh, B, 0, fpp(sep_out)))
+    for c in range(2):
+        assert rel_rms(sep_out[c], out[c]) < 2e-6
+    # a result buffer the caller pinned itself: the runtime refuses to register it again
+    from irbaboon_amd.engine import pinned_empty
+    pin = pinned_empty((2, La + Lh - 1))
+    _lib.check(lib.irb_convolve_periodic(0, fpp(xs), 2, La, hp, 2, Lh, B, 0, _lib.planar_ptrs(pin)))
+    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
+    assert rel_rms(pin, np.stack(out)) < 2e-6
+    lib.irb_release_cached_plans()
+
+
 def test_delta_ir_is_pure_delay():
     x = np.stack([white_noise(11, 8192), white_noise(12, 8192)])
     y = convolvePeriodic(x, delta_ir()[None], 256)
