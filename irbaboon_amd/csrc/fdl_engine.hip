@@ -1611,6 +1611,10 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
     if (env_int("IRB_OFFLINE_DIRECT", 1) != 0 && steps >= 2 && !last_piece_is_one_block) {
         const double t_reg = now_ms();
+        // (registering and unregistering host memory are device-wide operations for the runtime: with a resident real-time server
+        // alive on the device the call waited until that server's callbacks stopped -- 0.44 s in tests' phase 2 -- so the whole direct
+        // form sits in a quiet section: servers step aside for its ~0.3 ms, their callbacks take the one-launch form meanwhile)
+        DeviceQuiet quiet(device);
         HostRanges ranges;
         float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
         ranges.add(audio, audio_ch, (size_t) La);

@@ -81,7 +81,7 @@ def main():
     # the one-shot call's device timeline (last call of the traced run): kernels and copies in start order
     kt = stats_csv(os.path.join(P, "oneshot_kt"), "_kernel_trace.csv")
     if kt:
-        rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
+        rows = sorted((r for r in csv.DictReader(open(kt)) if r["Start_Timestamp"].isdigit()), key=lambda r: int(r["Start_Timestamp"]))
         last_ir = max(i for i, r in enumerate(rows) if "k_ir_fft" in r["Kernel_Name"])
         first = last_ir
         while first > 0 and int(rows[last_ir]["Start_Timestamp"]) - int(rows[first - 1]["Start_Timestamp"]) < 100000:

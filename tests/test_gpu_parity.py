@@ -440,26 +440,56 @@ def test_resident_server_yields_to_every_other_entry_point():
     assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
 
 
+def _other_handles_work(marks, tag):
+    """what a second plug-in instance and an offline tool do in the same process: three releaseResources + prepareToPlay of another
+    adapter (Source/PluginProcessor.cpp:164-248), a one-shot convolvePeriodic that builds its engine, its release, an unrelated
+    engine's create / step / destroy.  Returns the one-shot's result for a parity check."""
+    import time
+    import irbaboon_amd
+    xs, hs = white_noise(49, 48000)[None], decaying_ir(50, 12000)[None]
+    yo_ref = scipy.signal.fftconvolve(xs[0].astype(np.float64), hs[0].astype(np.float64))[None]
+    t0 = time.perf_counter()
+    Bc = RtConvolver(2, 256, 2048)
+    Bc.prepareToPlay(256)
+    marks[tag + "B create + prepareToPlay"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        Bc.releaseResources()
+        Bc.prepareToPlay(256)
+    marks[tag + "3x B.releaseResources + B.prepareToPlay"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    yo = convolvePeriodic(xs, hs, 256, keep_reference_tail=False)   # builds the calling thread's engine (hipMalloc, hipHostMalloc, streams)
+    marks[tag + "convolvePeriodic (engine built)"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    irbaboon_amd.lib().irb_release_cached_plans()                # ... and frees it (hipFree, hipHostFree)
+    marks[tag + "irb_release_cached_plans"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with FdlEngine(4, 1, 256, 24000) as e2:                      # an unrelated engine: create, one step, destroy
+        e2.set_ir(0, hs[0])
+        e2.process(xs[:, :256].repeat(4, axis=0))
+    marks[tag + "FdlEngine create + step + destroy"] = time.perf_counter() - t0
+    Bc.close()
+    return yo, yo_ref
+
+
 def test_resident_server_does_not_stall_other_handles():
     """A live k_rt_server holds its stream for as long as callbacks keep coming, and hipFree / hipHostFree wait for every stream of
     the device.  Adapter A streams 256-sample callbacks from its own thread (default: resident server) while the main thread does
-    what a second plug-in instance and an offline tool do in the same process: releaseResources + prepareToPlay on adapter B
-    (Source/PluginProcessor.cpp:164-248) several times, one convolvePeriodic that has to build its engine and one that
-    releases it again.  None of it may wait for A's server (the library brackets its device-wide waits with quiet sections:
-    the server steps aside, A's callbacks take the one-launch form meanwhile), and A's samples must be those of the
-    restated processBlock throughout.  The measured times go to gpurun_out/resident_vs_process.txt."""
+    what a second plug-in instance and an offline tool do in the same process (_other_handles_work).  None of it may wait for A's
+    server (the library brackets its device-wide waits with quiet sections: the server steps aside, A's callbacks take the
+    one-launch form meanwhile).  Phase 1: A driven block by block from Python, every sample checked against the restated
+    processBlock.  Phase 2: A's callbacks issued and timed in C (irb_rt_time_callbacks: no interpreter lock between the audio
+    thread and its clock) while the same work runs again -- A's slowest callback must stay inside its 5.3 ms period.
+    The measured times go to gpurun_out/resident_vs_process.txt (IRB_DEVICE_QUIET=0: the same without the brackets, recorded, not asserted)."""
     import threading
     import time
-    import irbaboon_amd
     ir = decaying_ir(5, 8 * 256)
     n_cb = 6000
     x = np.stack([white_noise(47, n_cb * 256), white_noise(48, n_cb * 256)])
     A = RtConvolver(2, 256, 2048)
     A.prepareToPlay(256)
     A.setIR(ir)
-    Bc = RtConvolver(2, 256, 2048)
-    Bc.prepareToPlay(256)
-    stop, done_cb, cb_ms, y = threading.Event(), [0], [], np.zeros_like(x)
+    stop, done_cb, y = threading.Event(), [0], np.zeros_like(x)
     errs = []
 
     def audio_thread():
@@ -468,9 +498,7 @@ def test_resident_server_does_not_stall_other_handles():
                 if stop.is_set():
                     break
                 blk = np.ascontiguousarray(x[:, k * 256:(k + 1) * 256])
-                t0 = time.perf_counter()
                 A.processBlock(blk)
-                cb_ms.append((time.perf_counter() - t0) * 1e3)
                 y[:, k * 256:(k + 1) * 256] = blk
                 done_cb[0] = k + 1
         except Exception as e:                                   # noqa: BLE001 -- reported by the main thread
@@ -480,34 +508,12 @@ def test_resident_server_does_not_stall_other_handles():
     th.start()
     while done_cb[0] < 200 and th.is_alive():                    # the server is up and in its steady state
         time.sleep(0.001)
-    c0 = A.counters()
     marks = {}
-    xs, hs = white_noise(49, 48000)[None], decaying_ir(50, 12000)[None]
-    t0 = time.perf_counter()
-    for _ in range(3):
-        Bc.releaseResources()
-        Bc.prepareToPlay(256)
-    marks["3x B.releaseResources + B.prepareToPlay"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    yo = convolvePeriodic(xs, hs, 256, keep_reference_tail=False)   # builds the calling thread's engine (hipMalloc, hipHostMalloc, streams)
-    marks["convolvePeriodic (engine built)"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    irbaboon_amd.lib().irb_release_cached_plans()                # ... and frees it (hipFree, hipHostFree)
-    marks["irb_release_cached_plans"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    with FdlEngine(4, 1, 256, 24000) as e2:                      # an unrelated engine: create, one step, destroy
-        e2.set_ir(0, hs[0])
-        e2.process(xs[:, :256].repeat(4, axis=0))
-    marks["FdlEngine create + step + destroy"] = time.perf_counter() - t0
-    cb_during = done_cb[0]
-    time.sleep(0.05)                                             # A goes back to the resident form
-    c1 = A.counters()
+    yo, yo_ref = _other_handles_work(marks, "phase 1 (Python audio thread): ")
     stop.set()
     th.join(timeout=60)
     assert not th.is_alive() and not errs, errs
     n_done = done_cb[0]
-    Bc.close()
-    A.close()
     ref = oracle.RtProcessor(2, 256, 2048)
     ref.prepare_to_play(256)
     ref.set_ir(ir)
@@ -518,11 +524,32 @@ def test_resident_server_does_not_stall_other_handles():
         yr[:, k * 256:(k + 1) * 256] = b
     for c in range(2):
         assert rel_rms(y[c, :n_done * 256], yr[c]) < RMS_TOL
-    assert rel_rms(yo[0], direct_f64(xs, hs)[0]) < RMS_TOL
-    cb = np.array(cb_ms)
+    assert rel_rms(yo[0], yo_ref[0]) < RMS_TOL
+    # ---- phase 2: the audio thread is ONE C call (60 000 callbacks issued and timed inside the library)
+    us, box = [None], []
+
+    def audio_thread_c():
+        try:
+            us[0] = A.time_callbacks(256, 60000)
+        except Exception as e:                                   # noqa: BLE001
+            box.append(e)
+
+    c0 = A.counters()
+    th = threading.Thread(target=audio_thread_c)
+    th.start()
+    time.sleep(0.02)
+    t_work = time.perf_counter()
+    _other_handles_work(marks, "phase 2 (C audio thread): ")
+    t_work = time.perf_counter() - t_work
+    th.join(timeout=120)
+    assert not th.is_alive() and not box, box
+    c1 = A.counters()
+    A.close()
+    cb = us[0].astype(np.float64)
     lines = [f"{k}: {v * 1e3:.2f} ms" for k, v in marks.items()]
-    lines.append(f"adapter A: {n_done} callbacks of 256 samples ({cb_during - 200} of them while the main thread worked), median {np.median(cb) * 1e3:.1f} us, "
-                 f"p99 {np.percentile(cb, 99) * 1e3:.1f} us, max {cb.max() * 1e3:.1f} us; launches in that window {c1[1] - c0[1]}, waits {c1[2] - c0[2]}")
+    lines.append(f"adapter A, phase 2: {cb.size} callbacks of 256 samples timed in C ({cb.sum() / 1e6:.2f} s, the other handles' work took {t_work:.2f} s of it): "
+                 f"median {np.median(cb):.1f} us, p99 {np.percentile(cb, 99):.1f} us, p99.9 {np.percentile(cb, 99.9):.1f} us, max {cb.max():.1f} us; "
+                 f"kernel launches {c1[1] - c0[1]} (callbacks served by one launch each while a quiet section was open, server restarts)")
     unprotected = os.environ.get("IRB_DEVICE_QUIET") == "0"      # diagnostic run: quiet sections switched off, times recorded, not asserted
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "resident_vs_process" + ("_unprotected" if unprotected else "") + ".txt"), "w") as f:
@@ -531,8 +558,8 @@ def test_resident_server_does_not_stall_other_handles():
     if unprotected:
         return
     # a stall behind the server would be its lifetime cap (250 ms) per device-wide wait: dozens of frees -> seconds
-    assert sum(marks.values()) < 1.5, marks
-    assert cb.max() < 100.0, cb.max()                            # ms: no callback was held up for a server lifetime either
+    assert sum(marks.values()) < 3.0, marks
+    assert cb.max() < 5333.0, cb.max()                           # us: every callback inside its period at 48 kHz
 
 
 def test_rt_adapter_host_block_larger_than_block_is_causal():

@@ -4,9 +4,11 @@
 # kernel + copy trace, registration cost), counters of the 8-blocks-per-call kernel in both forms, stamps / trace / counters / A-B
 # of the matrix-core MAC, what a live resident server does to other handles with and without quiet sections, the accuracy table.
 # Outputs under gpurun_out/prof_r04/ (profiles/collect_r04.py turns them into profiles/r04_*).
+# (gpurun copies at most 64 MiB back: the raw traces stay in /tmp on the box, only stats / summaries / the counters go to gpurun_out)
 R=/root/repo
-O=$R/gpurun_out/prof_r04
-rm -rf $O $R/gpurun_out/mfma_trace $R/gpurun_out/mfma_pmc; mkdir -p $O
+O=/tmp/prof_r04_raw
+K=$R/gpurun_out/prof_r04
+rm -rf $O $K $R/gpurun_out/mfma_trace $R/gpurun_out/mfma_pmc $R/gpurun_out/tiled8_pmc_*; mkdir -p $O $K
 cd $R
 echo "== bench (plain), then the same command under kernel-trace"
 python3 bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
@@ -42,4 +44,11 @@ IRB_DEVICE_QUIET=0 timeout -k 10 200 python3 -m pytest tests/test_gpu_parity.py 
 echo "== real-time callback, accuracy"
 (for hb in 64 256 512 1024; do python3 tools/perf_probe.py rtc $hb 3000; IRB_RT_RESIDENT=0 python3 tools/perf_probe.py rtc $hb 3000; done) > $O/rt_ab.txt 2>&1
 python3 tools/accuracy_report.py > /dev/null 2>&1; cp gpurun_out/accuracy.txt $O/accuracy.txt
+echo "== keep: line, stats, counters, summaries"
+cp $O/*.json $O/*.txt $O/*.err $O/*.log $K/ 2>/dev/null
+for d in bench_kt tests_kt oneshot_kt; do mkdir -p $K/$d/x; f=$(ls -S $O/$d/*/*_kernel_stats.csv | head -1); cp $f $K/$d/x/; done
+f=$(ls -S $O/oneshot_kt/*/*_kernel_trace.csv | head -1); tail -n +2 $f | tail -n 400 > /tmp/tail.csv; (head -1 $f; cat /tmp/tail.csv) > $K/oneshot_kt/x/oneshot_kernel_trace.csv
+for c in FETCH_SIZE WRITE_SIZE; do mkdir -p $K/pmc_$c/x; for f in $O/pmc_$c/*/*_counter_collection.csv; do (head -1 $f; grep k_step_fused $f) > $K/pmc_$c/x/$(basename $f); done; done
+rm -rf $R/gpurun_out/tiled8_pmc_fused $R/gpurun_out/tiled8_pmc_three_launches $R/gpurun_out/mfma_trace/kt_*/ $R/gpurun_out/mfma_pmc
+du -sh $R/gpurun_out | tail -1
 echo done
