@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r03_bench.json, copied from a real MI355X run) keeps the driver's
+"""The committed bench line (profiles/r04_bench.json, copied from a real MI355X run) keeps the driver's
 contract: required keys, types, and internal consistency of the roofline / cpu_baseline objects."""
 import json
 import os
@@ -7,12 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "n_gpus_visible", "steps", "warmup", "ms_per_step", "ms_per_step_wall", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_spot", "pcie_inclusive", "environment"):
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "n_gpus_visible", "steps", "warmup", "ms_per_step", "ms_per_step_device_events", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores", "parity_spot", "pcie_inclusive",
+              "environment", "setup_s_per_device"):
         assert k in d, k
     assert d["environment"]["library"].endswith("libirbfdl.so") and d["environment"]["irb_env"] == {}     # no tuning override behind the line
-    assert abs(d["ms_per_step"] - d["roofline"]["kernel_ms"]) < 1e-3 and 0.98 < d["ms_per_step_wall"] / d["ms_per_step"] < 1.05
+    # value follows the host wall clock (the contract's clock); the device's own events feed the roofline entry and agree with it
+    assert abs(d["ms_per_step_device_events"] - d["roofline"]["kernel_ms"]) < 1e-3 and 0.98 < d["ms_per_step"] / d["ms_per_step_device_events"] < 1.05
+    assert len(d["setup_s_per_device"]) == d["n_gpus"]
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "Msamples/s"
     assert d["vs_baseline"] is None and base["published"] == {}            # nothing published to compare with
@@ -36,6 +39,16 @@ def test_committed_bench_line_follows_contract():
     assert "-march=native" in c["cflags"]
     chain = d["other_configs"]["configs[4]_2^20_deconvolve_chain"]
     assert chain["samples"] == 1 << 20 and chain["deconvolve_default_3x_smoothing_ms"] > chain["deconvolve_no_smoothing_ms"] > 0
+    # the drop-in function itself (host buffers in, host buffers out), with its breakdown and the oracle's time beside it
+    for name, limit_ms in (("configs[0]_one_shot", 0.30), ("configs[1]_one_shot", 0.40)):
+        e = d["other_configs"][name]
+        assert 0 < e["wall_ms_c_abi_min"] <= e["wall_ms_c_abi"] <= limit_ms and e["wall_ms_python_mirror"] <= limit_ms + 0.05
+        b = e["breakdown_ms"]
+        assert b["direct"] == 1 and b["mac_on_matrix_cores"] == 1 and b["pieces"] == 1 and b["steps"] == b["blocks_per_chunk"]
+        assert 0 < b["fft_in_ms"] and 0 < b["mac_ms"] and 0 < b["fft_out_ms"] and b["fft_in_ms"] + b["mac_ms"] + b["fft_out_ms"] <= b["device_ms"] * 1.02 <= b["total_ms"] * 1.02
+        assert e["cpu_oracle_ms_1_core"] > 20 * e["wall_ms_c_abi"]
+    assert d["other_configs"]["configs[1]_offline_one_stream"]["mac_kernel"] == "k_cmac_mfma"
+    assert d["other_configs"]["configs[1]_x2048_8_blocks_per_call"]["mac_kernel"] == "k_tile8_fused"
     # the two paths that had no number in the line
     rt = d["other_configs"]["rt_processBlock"]
     for hb, limit in ((256, 18.0), (512, 30.0)):
@@ -57,15 +70,15 @@ def test_committed_bench_line_follows_contract():
 
 
 def test_every_bench_kernel_is_launched_by_a_parity_test():
-    """profiles/r03_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
-    (profiles/collect_r03.py): no kernel is timed that the parity suite does not also run."""
-    lines = open(os.path.join(ROOT, "profiles", "r03_kernel_coverage.txt")).read().strip().splitlines()
+    """profiles/r04_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
+    (profiles/collect_r04.py): no kernel is timed that the parity suite does not also run."""
+    lines = open(os.path.join(ROOT, "profiles", "r04_kernel_coverage.txt")).read().strip().splitlines()
     assert lines[-1] == "bench kernels without a parity-test launch: 0"
     rows = [l for l in lines[1:-1] if "irb::" in l]
     assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
     assert any("k_step_fused<512, 2, true>" in l for l in rows) and any("k_step_cols<256, 4, 2" in l for l in rows)
     assert any("k_rt_pair<512" in l for l in rows) and any("k_cmac_mfma<512>" in l for l in rows) and any("k_cmac_mfma<256>" in l for l in rows)
-    assert any("k_cmac_tiled_pk<512, 8, 4, 4" in l for l in rows)
+    assert any("k_tile8_fused<512, true>" in l for l in rows) and any("k_push_fft_batch_t<512>" in l for l in rows)
     assert any("k_ifft_ola_run<512, 4>" in l for l in rows) and any("k_lfft_rows_split<1024, 4>" in l for l in rows)
 
 
