@@ -199,7 +199,10 @@ int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_float
  * [audio_ch][La+Lh-1].  keep_reference_tail != 0 reproduces the reference's
  * dropped tail (only (floor(La/B)+P)*B samples are written, the rest stay 0,
  * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.
- * The calling thread's engine (device buffers, pinned staging, stream) is kept for the next call of a similar size;
+ * `out` must not overlap `audio` (the reference returns a new buffer; IRB_ERR_ARG otherwise).  For the duration of the call the
+ * audio and result buffers are registered with the HIP runtime and the kernels read / write them in place (no host copy of the
+ * signal); where the runtime refuses that, the call goes through pinned staging instead (irb_convolve_last_profile tells).
+ * The calling thread's engine (device buffers, pinned staging, streams) is kept for the next call of a similar size;
  * it is freed by irb_release_cached_plans() (irb_deconv.h) or when the thread exits.        */
 int  irb_convolve_periodic(int device,
                            const float *const *audio, int audio_ch, int La,

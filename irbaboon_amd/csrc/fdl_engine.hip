@@ -559,7 +559,7 @@ int launch_ht(irb_fdl *h, int first_set, int nsets, int np)
     h->n_launches++;
     const int nrows = h->ht_len - 16;
     const dim3 grid(nrows / 16, h->M >= 64 ? h->M / 64 : 1, nsets);
-    FOR_N(h->N, irb::k_rows_to_columns<NN / 2, false><<<grid, dim3(256), 0, h->stream>>>(h->d_H + (size_t) first_set * h->Ppad * h->M, (long) h->Ppad * h->M, 0, 0, np,
+    FOR_N(h->N, irb::k_rows_to_columns<NN / 2><<<grid, dim3(256), 0, h->stream>>>(h->d_H + (size_t) first_set * h->Ppad * h->M, (long) h->Ppad * h->M, 0, 0, np,
                                                                                    h->d_Ht + (size_t) first_set * h->M * h->ht_len, (long) h->M * h->ht_len, h->ht_len, 16, nrows));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
@@ -1538,6 +1538,10 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         clear_out(0);
         return fail(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
     }
+    for (int c = 0; c < audio_ch; c++)                                              // (the reference returns a NEW buffer: result and audio never share samples)
+        for (int d = 0; d < audio_ch; d++)
+            if (audio[d] && La > 0 && Lout > 0 && out[c] < audio[d] + La && audio[d] < out[c] + Lout)
+                return fail(IRB_ERR_ARG, "out[%d] overlaps audio[%d]: the result buffer must not alias the audio", c, d);
     if (Lh == 0 || La == 0 || Lout <= 0) { clear_out(0); return IRB_OK; }           // nothing to convolve: the cleared output is the answer
     // :52 -- the reference takes ceil of a float ratio; samples beyond P*B are never read (:106-118)
     const int P = (int) std::ceil((float) Lh / (float) B);

@@ -17,7 +17,7 @@
 // kernels that produce them:
 //     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin, permuted inside every segment of 16 blocks (mfma_xt_pos)
 //                                    (k_push_fft_batch_t; the blocks before the call's first one sit in [0, xt_hist): rebuilt from
-//                                    the ring by k_rows_to_columns when there are any)
+//                                    the ring by extra workgroups of that launch when there are any)
 //     Ht[set][bin][16 + m]           the IR spectra with the tap index contiguous per bin, 16 zero taps in front, zeros behind
 //                                    (k_rows_to_columns at irb_fdl_set_ir*)
 // A wave owns ONE bin of one tile of 256 output blocks and one range of chunks, and nothing it reads is shared with another
@@ -64,13 +64,12 @@ __host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chu
 __host__ __device__ constexpr int mfma_xt_pos(int t) { return (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3); }
 
 // ---------------------------------------------------------------------------------------------
-// k_rows_to_columns: rows [r0, r0 + nrows) of a [row][M] spectrum array (ring addressed: physical row (first + r) mod R) become
-// columns [c0 + r] of a [M][ldc] array; rows at or beyond `valid` are written as zeros.  Used for Ht (IR spectra -> tap-contiguous,
-// at set-up) and for Xt's history (the FDL ring's last blocks -> time-contiguous, before a matrix-core call that continues a stream).
-// A workgroup transposes 16 rows x 64 bins through LDS: 512-byte pieces in, whole 128-byte lines out.
-// grid = (ceil(nrows / 16), M / 64 or 1, sets), block = 256.
+// k_rows_to_columns: rows [0, nrows) of a [row][M] spectrum array become columns [c0 + r] of a [M][ldc] array; rows at or beyond
+// `valid` are written as zeros.  Builds Ht (IR spectra -> tap-contiguous) at set-up.  A workgroup transposes 16 rows x 64 bins
+// through LDS: 512-byte pieces in, whole 128-byte lines out.  grid = (ceil(nrows / 16), M / 64 or 1, sets), block = 256.
+// (Xt's history columns are rebuilt from the FDL ring the same way by extra workgroups of k_push_fft_batch_t.)
 // ---------------------------------------------------------------------------------------------
-template <int M, bool PERM>
+template <int M>
 __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restrict__ src, long src_set_stride, int first, int R, int valid,
                                                           float2 *__restrict__ dst, long dst_set_stride, int ldc, int c0, int nrows)
 {
@@ -92,9 +91,7 @@ __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restric
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * BW; e += 256) {
         const int b = e / 16, r = e % 16;
-        // PERM (Xt): inside each group of 16 columns position q holds row mfma_xt_pos(q) (a 4 x 4 transpose: its own inverse; c0, r0
-        // and nrows are multiples of 16 there)
-        if (r0 + r < nrows) d[(size_t) (b0 + b) * ldc + c0 + r0 + r] = l_t[PERM ? mfma_xt_pos(r) : r][b];
+        if (r0 + r < nrows) d[(size_t) (b0 + b) * ldc + c0 + r0 + r] = l_t[r][b];
     }
 }
 
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     const int groups = (a.t_count + NBW - 1) / NBW;
     if ((int) blockIdx.x >= S * groups) {
         // extra workgroups of a call that continues a stream (a.hist_first >= 0): the xt_hist blocks before the call's first one go
-        // from the FDL ring into Xt's history columns -- k_rows_to_columns<M, true>'s work without a launch of its own, 16 ring
+        // from the FDL ring into Xt's history columns (k_rows_to_columns' transpose, plus the segment permutation), 16 ring
         // rows x 64 bins per workgroup through LDS
         constexpr int BW = M < 64 ? M : 64, BY = M / BW;
         float2 (*l_t)[BW + 1] = reinterpret_cast<float2 (*)[BW + 1]>(&l_buf[0][0]);

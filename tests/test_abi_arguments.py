@@ -105,3 +105,16 @@ def test_multi_group_arguments():
     dev = (C.c_int * 3)(0, 0, 0)
     assert L.irb_fdl_multi_create(C.byref(c), dev, 3, C.byref(m)) == _lib.IRB_ERR_ARG      # more devices than instances
     assert L.irb_fdl_multi_create(C.byref(c), dev, 0, C.byref(m)) == _lib.IRB_ERR_ARG
+
+
+def test_convolve_periodic_refuses_a_result_buffer_that_aliases_the_audio():
+    """fp::convolution::convolvePeriodic returns a NEW AudioBuffer (fp/convolution.cpp:20-21): result and audio never share samples, and
+    the kernels read the one while they write the other.  An overlapping `out` is an argument error, reported before any HIP call."""
+    big = np.zeros(3000, np.float32)
+    audio, out = big[100:1100][None], big[600:600 + 1000 + 50 - 1][None]          # La = 1000, Lh = 50: out overlaps the audio's second half
+    h = np.ones((1, 50), np.float32)
+    rc = L.irb_convolve_periodic(0, planar_ptrs(audio), 1, 1000, planar_ptrs(h), 1, 50, 16, 1, planar_ptrs(out))
+    assert rc == _lib.IRB_ERR_ARG and "alias" in _err()
+    p = _lib.ConvolveProfile()
+    assert L.irb_device_quiet_begin(-1) == _lib.IRB_ERR_ARG and L.irb_device_quiet_end(0) == _lib.IRB_ERR_STATE       # unbalanced end, bad device
+    assert L.irb_convolve_last_profile(None) == _lib.IRB_ERR_ARG
