@@ -33,9 +33,37 @@ while time.time() - t0 < budget:
     env["IRB_TILED_MFMA_MIN_T"] = str(rng.choice([0, 2, 2]))    # off / the matrix-core tiled MAC for every call of >= 2 blocks
     env["IRB_TILED_MFMA_WGS"] = str(rng.choice([16, 256, 2048]))
     env["IRB_TILED_MFMA_MIN_CHUNKS"] = str(rng.choice([1, 6]))
-    for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS", "IRB_TILED_KERNEL", "IRB_FUSED_U", "IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS"):
+    env["IRB_TILED_MFMA_TWO_LAUNCH"] = str(rng.choice([0, 1, 1]))   # whole rounds + remainder launch of the matrix-core MAC
+    env["IRB_TILED_MFMA_RES"] = str(rng.choice([1, 1, 2]))
+    env["IRB_TILED_FUSED8"] = str(rng.choice([0, 1, 1]))            # calls of <= 8 blocks as one launch / three
+    for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS", "IRB_TILED_KERNEL", "IRB_FUSED_U", "IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS",
+              "IRB_TILED_MFMA_TWO_LAUNCH", "IRB_TILED_MFMA_RES", "IRB_TILED_FUSED8", "IRB_OFFLINE_DIRECT", "IRB_OFFLINE_MAX_BLOCKS", "IRB_OFFLINE_CHUNK", "IRB_OFFLINE_HELPER"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    if n % 4 == 3:
+        # the one-shot function (irb_convolve_periodic) in both forms, in one or several pieces, with and without the reference's dropped tail
+        from irbaboon_amd import convolvePeriodic
+        Bo = int(rng.choice([8, 16, 32, 100, 128, 256, 512]))
+        Ca, Ci = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        La, Lho = int(rng.integers(1, 300 * Bo)), int(rng.integers(1, 40 * Bo))
+        oenv = {"IRB_OFFLINE_DIRECT": str(rng.choice([0, 1, 1])), "IRB_OFFLINE_HELPER": str(rng.choice([0, 1])), "IRB_OFFLINE_CHUNK": str(rng.choice([16, 64, 1024]))}
+        if rng.integers(0, 3) == 0:
+            oenv["IRB_OFFLINE_MAX_BLOCKS"] = str(rng.choice([5, 40, 700]))
+        os.environ.update(oenv)
+        keep = bool(rng.integers(0, 2))
+        xa = np.stack([white_noise(int(rng.integers(1 << 30)), La) for _ in range(Ca)])
+        ha = np.stack([decaying_ir(int(rng.integers(1 << 30)), Lho) for _ in range(Ci)])
+        yo = convolvePeriodic(xa, ha, Bo, keep_reference_tail=keep)
+        nw = min(La + Lho - 1, (La // Bo + -(-Lho // Bo)) * Bo) if keep else La + Lho - 1
+        for c in range(Ca):
+            hh = ((ha[0].astype(np.float32) + ha[1]) / np.float32(2)).astype(np.float64) if (Ci == 2 and Ca == 1) else ha[c if Ci == Ca else 0].astype(np.float64)
+            ref = scipy.signal.fftconvolve(xa[c].astype(np.float64), hh)
+            den = np.sqrt(np.mean(ref[:nw] ** 2))
+            err = np.sqrt(np.mean((yo[c, :nw] - ref[:nw]) ** 2)) / den if den > 0 else np.abs(yo[c, :nw]).max()
+            worst = max(worst, err)
+            assert err < 1e-5 and not yo[c, nw:].any(), ("one-shot", Bo, Ca, Ci, La, Lho, keep, oenv, err)
+        _lib.lib().irb_release_cached_plans()
+        counts["one-shot"] = counts.get("one-shot", 0) + 1
     ir_ch = int(rng.integers(1, 3))
     x = np.stack([white_noise(int(rng.integers(1 << 30)), T * B) for _ in range(I * C)])
     irs = [np.stack([decaying_ir(int(rng.integers(1 << 30)), Lh) for _ in range(ir_ch)]) for _ in range(I)]
