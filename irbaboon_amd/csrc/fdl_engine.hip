@@ -1201,12 +1201,20 @@ int irb_fdl_reset(irb_fdl *h)
     if (!h) return fail(IRB_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     STOP_SERVER(h);
-    HIP_TRY(hipMemsetAsync(h->d_X, 0, sizeof(float2) * (size_t) h->S * h->M * h->R, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream));
-    if (h->d_Xt)                                    // the blocks "before" the next call: zero, like the ring (the columns of the calls themselves are rewritten by every call)
-        HIP_TRY(hipMemset2DAsync(h->d_Xt, sizeof(float2) * h->xt_len, 0, sizeof(float2) * h->xt_hist, (size_t) h->S * h->M, h->stream));
-    if (h->d_gran)                                  // the step counter restarts, and with it the granule tags
-        HIP_TRY(hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream));
+    // one launch: the ring, both overlaps, (matrix-core engines) the blocks "before" the next call in Xt -- the columns of the calls
+    // themselves are rewritten by every call --, (column-sliced engines) the granule tags: the step counter restarts
+    irb::ResetArgs r;
+    std::memset(&r, 0, sizeof r);
+    const size_t ovl_bytes = sizeof(float) * (size_t) 2 * h->S * h->B;
+    r.p[0] = reinterpret_cast<float4 *>(h->d_X);   r.n16[0] = sizeof(float2) * (size_t) h->S * h->M * h->R / 16;        // (M >= 16: rows are multiples of 16 bytes)
+    r.p[1] = reinterpret_cast<float4 *>(h->d_ovl); r.n16[1] = ovl_bytes / 16;
+    if (h->d_gran) { r.p[2] = reinterpret_cast<float4 *>(h->d_gran); r.n16[2] = sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N / 16; }
+    if (h->d_Xt) { r.xt = reinterpret_cast<float4 *>(h->d_Xt); r.rows = (size_t) h->S * h->M; r.pitch16 = (size_t) h->xt_len / 2; r.hist16 = (size_t) h->xt_hist / 2; }
+    h->n_launches++;
+    const size_t work = r.n16[0] + r.n16[1] + r.n16[2] + r.rows * r.hist16;
+    irb::k_reset<<<dim3((unsigned) std::min<size_t>(2048, (work + 255) / 256 + 1)), dim3(256), 0, h->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+    if (ovl_bytes % 16) HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(h->d_ovl) + ovl_bytes / 16 * 16, 0, ovl_bytes % 16, h->stream));   // (2 S B floats not a multiple of 4: the last few bytes)
     h->t = 0;
     h->ovl_cur = 0;
     return IRB_OK;

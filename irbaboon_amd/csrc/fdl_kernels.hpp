@@ -1338,6 +1338,28 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ifft_ola_batch(StepA
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_reset: what a fresh convolvePeriodic call starts from (fp/convolution.cpp:59,67,81,87) in ONE launch: the FDL ring, both overlap
+// buffers, the history columns of the matrix-core path's transposed FDL, the granule tags of the column-sliced step.  Four runtime
+// memsets cost four launches of ~4-5 us each in front of every one-shot call; the bytes themselves are a few microseconds.
+// Segments of 16 bytes, grid-stride.
+// ---------------------------------------------------------------------------------------------
+struct ResetArgs {
+    float4 *p[3];                // linear regions (ring, overlap, granules): pointers (16-byte aligned: hipMalloc) ...
+    size_t n16[3];               // ... and lengths in 16-byte units (0: none)
+    float4 *xt;                  // Xt rows: `rows` rows of `pitch16` units, of which the first `hist16` are cleared
+    size_t rows, pitch16, hist16;
+};
+
+__global__ __launch_bounds__(256) void k_reset(ResetArgs r)
+{
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t tid = (size_t) blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t) gridDim.x * blockDim.x;
+    for (int k = 0; k < 3; k++)
+        for (size_t i = tid; i < r.n16[k]; i += nth) r.p[k][i] = z;
+    for (size_t i = tid; i < r.rows * r.hist16; i += nth) r.xt[(i / r.hist16) * r.pitch16 + i % r.hist16] = z;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_ir_fft: IR partitions -> spectra (reference fp/convolution.cpp:106-125).  one wave per partition:
 // row r of `ir` (time domain, [n_rows][P*B], zero padded) -> H set first_set + r.
 // ---------------------------------------------------------------------------------------------
