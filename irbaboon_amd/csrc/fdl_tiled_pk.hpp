@@ -195,22 +195,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_cmac_tiled_pk(StepArgs a)
 // spectra per stream, flushed them at two kernel boundaries and read them back (profiles/r04_tiled8_pmc.txt: 18 + 24 us of
 // 572 and 67 MB of 3.3 GB at 2048 streams).  grid = S, block = 256; 256 <= N <= 1024.
 // ---------------------------------------------------------------------------------------------
-template <int N, bool NT>
-__global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
+// phase A of k_tile8_fused*: the four waves transform the call's blocks (two each) into the FDL ring; ends with a workgroup barrier
+// that also drains the stores (the new rows are in the L2 before any wave of this workgroup loads them)
+template <int N, int TT>
+__device__ __forceinline__ void tile8_push(const StepArgs &a, int s, float2 (&l_buf)[TT][N / 2], float2 *l_tw, int wave, int lane)
 {
-    using G = MacGeom<N>;
-    constexpr int M = N / 2, TT = 8, U = 4, WAVES = kThreads / kWave, PER = TT / WAVES;
-    constexpr int VPL = M > kWave ? M / kWave : 1;     // samples per lane of a half block (B <= M)
-    static_assert(G::CPT == 1 && N >= 256, "one column block per thread");
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[TT][M];
-    __shared__ float4 l_red[G::STRIPES > 1 ? G::STRIPES - 1 : 1][TT][G::LW];
-    const int s = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-    const int2 si = a.stream_info[s];
-    const int set = si.x, np = si.y;
-    const float scale = 1.0f / (float) N;
-    // ---- A: forward FFTs of blocks wave, wave + 4
+    constexpr int M = N / 2, WAVES = kThreads / kWave, PER = TT / WAVES;
     TwiddleStage<N, kThreads> tws;
     tws.load(a.tw);
 #pragma unroll
@@ -229,7 +219,61 @@ __global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
             wave_split_forward<M>(l_buf[j], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
         }
     }
-    __syncthreads();                                   // (drains the stores: the new rows are in the L2 before any wave of this workgroup loads them)
+    __syncthreads();
+}
+
+// phase D: the eight summed spectra in l_buf -> inverse FFTs (two per wave, fp/convolution.cpp:206), overlap-add (:209-213):
+// out[j] = y_j[0:B] + y_(j-1)[B:2B], block 0 adds the overlap the previous call saved, the last block's second half is saved
+template <int N, int TT>
+__device__ __forceinline__ void tile8_ifft_ola(const StepArgs &a, int s, float2 (&l_buf)[TT][N / 2], const float2 *l_tw, int wave, int lane)
+{
+    constexpr int M = N / 2, WAVES = kThreads / kWave, PER = TT / WAVES;
+    constexpr int VPL = M > kWave ? M / kWave : 1;     // samples per lane of a half block (B <= M)
+    const float scale = 1.0f / (float) N;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) {
+            wave_split_inverse<M>(l_buf[j], l_tw, lane);
+            wave_fft<M, true>(l_buf[j], l_tw, lane);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int j = wave + WAVES * r;
+        if (j < a.T) {
+            const float *y = reinterpret_cast<const float *>(l_buf[j]);
+            const float *yp = reinterpret_cast<const float *>(l_buf[j > 0 ? j - 1 : 0]);
+            const float *o = a.ovl + (size_t) s * a.B;           // (kept out of registers until here: the tile needs them all)
+            float *out = a.out + (long) s * a.out_stride + (long) j * a.B;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                const int n = lane + i * kWave;
+                if (n < a.B) out[n] = y[n] * scale + (j > 0 ? yp[a.B + n] * scale : o[n]);
+            }
+            if (j == a.T - 1) {
+                float *on = a.ovl_next + (size_t) s * a.B;
+                for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
+            }
+        }
+    }
+}
+
+template <int N, bool NT>
+__global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
+{
+    using G = MacGeom<N>;
+    constexpr int M = N / 2, TT = 8, U = 4;
+    static_assert(G::CPT == 1 && N >= 256, "one column block per thread");
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[TT][M];
+    __shared__ float4 l_red[G::STRIPES > 1 ? G::STRIPES - 1 : 1][TT][G::LW];
+    const int s = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    const int2 si = a.stream_info[s];
+    const int set = si.x, np = si.y;
+    tile8_push<N, TT>(a, s, l_buf, l_tw, wave, lane);                                  // ---- A
     // ---- B: the register tile over the stream's partitions, stripes = partition sub-ranges of whole ring periods
     const int col = threadIdx.x % G::LW;
     const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
@@ -266,35 +310,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
         }
     }
     __syncthreads();
-    // ---- D: inverse FFTs, overlap-add
-#pragma unroll
-    for (int r = 0; r < PER; r++) {
-        const int j = wave + WAVES * r;
-        if (j < a.T) {
-            wave_split_inverse<M>(l_buf[j], l_tw, lane);
-            wave_fft<M, true>(l_buf[j], l_tw, lane);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < PER; r++) {
-        const int j = wave + WAVES * r;
-        if (j < a.T) {
-            const float *y = reinterpret_cast<const float *>(l_buf[j]);
-            const float *yp = reinterpret_cast<const float *>(l_buf[j > 0 ? j - 1 : 0]);
-            const float *o = a.ovl + (size_t) s * a.B;           // block 0 adds the overlap the previous call saved (kept out of registers until here: the tile needs them all)
-            float *out = a.out + (long) s * a.out_stride + (long) j * a.B;
-#pragma unroll
-            for (int i = 0; i < VPL; i++) {
-                const int n = lane + i * kWave;
-                if (n < a.B) out[n] = y[n] * scale + (j > 0 ? yp[a.B + n] * scale : o[n]);
-            }
-            if (j == a.T - 1) {
-                float *on = a.ovl_next + (size_t) s * a.B;
-                for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
-            }
-        }
-    }
+    tile8_ifft_ola<N, TT>(a, s, l_buf, l_tw, wave, lane);                              // ---- D
 }
 
 // ---------------------------------------------------------------------------------------------
