@@ -88,6 +88,9 @@ struct StepArgs {
 #ifdef IRB_STAMPS
 __device__ __forceinline__ void stamp_(unsigned long long *buf, int i)
 {
+#ifdef IRB_STAMPS_ENDS_ONLY
+    if (i != 0 && i != 10) return;                   // (tools/clock_under_load.hip: a kernel's first and last stamp only -- the phase stamps' fences stay out of it)
+#endif
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
     const int2 si = a.stream_info[s];
     const int set = si.x, np = si.y;
+    IRB_STAMP(a, 0);
     tile8_push<N, TT>(a, s, l_buf, l_tw, wave, lane);                                  // ---- A
     // ---- B: the register tile over the stream's partitions, stripes = partition sub-ranges of whole ring periods
     const int col = threadIdx.x % G::LW;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
     }
     __syncthreads();
     tile8_ifft_ola<N, TT>(a, s, l_buf, l_tw, wave, lane);                              // ---- D
+    IRB_STAMP(a, 10);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ def main():
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             out.append(f"{(s - t0) / 1e3:8.1f}  +{(e - s) / 1e3:8.1f}   {r['Kernel_Name'][:90]}")
         open(os.path.join(HERE, "r04_oneshot_timeline.txt"), "w").write("\n".join(out) + "\n")
-    for src, dst in (("oneshot.txt", "r04_oneshot.txt"), ("pin_probe.txt", "r04_pin_probe.txt"), ("tiled8_pmc.txt", "r04_tiled8_pmc.txt"),
+    for src, dst in (("oneshot.txt", "r04_oneshot.txt"), ("pin_probe.txt", "r04_pin_probe.txt"), ("tiled8_pmc.txt", "r04_tiled8_pmc.txt"), ("clock_under_load.txt", "r04_clock_under_load.txt"),
                      ("mfma_stamps.txt", "r04_mfma_stamps.txt"), ("mfma_trace.txt", "r04_mfma_kernel_trace.txt"), ("mfma_pmc.txt", "r04_mfma_pmc.txt"),
                      ("mfma_ab.txt", "r04_mfma_ab.txt"), ("resident_vs_process.txt", "r04_resident_vs_process.txt"), ("rt_ab.txt", "r04_rt_callback_ab.txt"),
                      ("accuracy.txt", "r04_accuracy.txt")):

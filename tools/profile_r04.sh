@@ -32,6 +32,7 @@ echo "== one-shot function: forms, trace, registration cost"
 echo "== 8 blocks per call at 2048 instances: counters, one launch vs three"
 ./tools/tiled8_pmc.sh fused > /dev/null 2>&1; IRB_TILED_FUSED8=0 ./tools/tiled8_pmc.sh three_launches > /dev/null 2>&1
 cat gpurun_out/tiled8_pmc_fused.txt gpurun_out/tiled8_pmc_three_launches.txt > $O/tiled8_pmc.txt
+timeout -k 5 120 ./tools/clock_under_load 2048 > $O/clock_under_load.txt 2>&1
 echo "== matrix-core MAC: stamps, kernel trace of the offline calls, counters, A/B against the vector kernel"
 (for a in "3750 1 375" "4096 1 375" "1024 4 375" "2048 2 3750"; do timeout -k 5 60 ./tools/mfma_stamps $a; done; echo "== the same kernel with no loads in its loop (timing only)"; timeout -k 5 60 ./tools/mfma_stamps_exp2 3750 1 375) > $O/mfma_stamps.txt 2>&1
 ./tools/mfma_trace.sh "256 96000 3750 1 100" "256 96000 4125 1 100" "256 96000 1024 1 100" "128 480000 2048 2 50" "256 96000 1024 16 20" > $O/mfma_trace.txt 2>&1
