@@ -1,8 +1,8 @@
 """The drop-in function as a maintainer binds it: irb_convolve_periodic (fp::convolution::convolvePeriodic, fp/convolution.hpp:31)
 from pageable host buffers, wall clock, with the library's own breakdown of the call.
 usage: python tools/oneshot_probe.py [cfg0|cfg1|cfg2|all] [reps]
-Pipeline overrides are read from the environment per call: IRB_OFFLINE_CHUNK, IRB_OFFLINE_MODE (0 staged copies, 1 zero copy),
-IRB_OFFLINE_HELPER, IRB_OFFLINE_SLOTS (a changed slot count re-creates the cached engine)."""
+Pipeline overrides are read from the environment per call: IRB_OFFLINE_CHUNK,
+IRB_OFFLINE_HELPER (the staged form), IRB_OFFLINE_DIRECT=0 (staged form instead of the caller's registered memory), IRB_OFFLINE_MAX_BLOCKS."""
 import ctypes as C
 import os
 import sys
