@@ -258,6 +258,9 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
                                           "configs[0] (the reference's CPU plumbing case: mono, B=256, Lh=4096, 10 s of audio) through the drop-in function")
     res["configs[1]_one_shot"] = one_shot(dev, np, decaying_ir, white_noise, 1, 1, 256, 96000, 960000,
                                           "configs[1] (mono, B=256, 2 s IR, 20 s of audio) through the drop-in function")
+    res["configs[2]_one_shot"] = one_shot(dev, np, decaying_ir, white_noise, 2, 2, 128, 480000, 1920000,
+                                          "configs[2] (stereo, B=128, 10 s IR, 40 s of audio: 18750 block steps = two multiplies, the FDL carried "
+                                          "between them) through the drop-in function", reps=7)
     res["rt_processBlock"] = rt_process_block(dev, np)
     res.update(config5(dev, np))
     return res
