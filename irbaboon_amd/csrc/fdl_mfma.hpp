@@ -15,7 +15,7 @@
 // rest went to the first stage's burst, ~700 cycles per barrier round, a window re-loaded per stage and LDS operand reads
 // between the MFMAs.  Here the two operands are kept a SECOND time in the layout the instruction wants, written once by the
 // kernels that produce them:
-//     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin, permuted inside every segment of 16 blocks (mfma_xt_pos)
+//     Xt[stream][bin][xt_hist + t]   the FDL with time contiguous per bin, re / im planar inside every segment of 16 blocks (mfma_xt_float)
 //                                    (k_push_fft_batch_t; the blocks before the call's first one sit in [0, xt_hist): rebuilt from
 //                                    the ring by extra workgroups of that launch when there are any)
 //     Ht[set][bin][16 + m]           the IR spectra with the tap index contiguous per bin, 16 zero taps in front, zeros behind
@@ -55,13 +55,17 @@ constexpr int kMfmaOS = kMfmaBins + 1;                 // row stride of the outp
 __host__ __device__ constexpr int mfma_chunks(int np) { return np > 0 ? (np + kMfmaSeg - 2) / kMfmaSeg + 1 : 0; }
 // blocks of history in front of a call's first block in Xt: chunk J - 1 of tile 0 reads back to -16 (J - 1), the loads that run
 // ahead of the last chunk to -16 (J + 1) -- everything the kernel addresses exists, nothing depends on buffer range checks
-__host__ __device__ constexpr int mfma_hist(int P) { return kMfmaSeg * (mfma_chunks(P) + 2); }
+__host__ __device__ constexpr int mfma_hist(int P) { return kMfmaSeg * (mfma_chunks(P) + 3); }
 // taps per bin row of Ht: 16 zeros, the taps, zeros up to the last index the run-ahead loads read (16 + 16 (J + 1) + 15)
-__host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chunks(P) + 3); }
+__host__ __device__ constexpr int mfma_taps(int P) { return kMfmaSeg * (mfma_chunks(P) + 4); }
 
-// position of block t inside its segment of 16 in Xt: [t % 4][t / 4 % 4] instead of time order, so that the four k groups an
-// operand lane (n, kq) needs -- blocks 4 g + kq, g = 0 .. 3, of one segment -- are 32 contiguous bytes
-__host__ __device__ constexpr int mfma_xt_pos(int t) { return (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3); }
+// Xt inside every segment of 16 blocks (32 floats): component c (0 re, 1 im) of block 4 g + kq is float 8 kq + 4 c + g, so that the
+// four k groups an operand lane (n, kq) needs -- blocks 4 g + kq, g = 0 .. 3, of one segment -- are 16 contiguous bytes of real
+// parts followed by 16 of imaginary parts (two dwordx4 loads; re + im of two k groups is then one v_pk_add_f32)
+__host__ __device__ constexpr int mfma_xt_float(int t, int c) { return ((t & ~15) << 1) | ((t & 3) << 3) | (c << 2) | ((t >> 2) & 3); }
+// the 8-byte slot p < 16 of a segment therefore holds component (p >> 1) & 1 of the blocks mfma_xt_slot_block(p) and that + 4
+__host__ __device__ constexpr int mfma_xt_slot_block(int p) { return ((p & 1) << 3) | (p >> 2); }
+__device__ __forceinline__ float mfma_component(const float2 &v, int c) { return c ? v.y : v.x; }
 
 // ---------------------------------------------------------------------------------------------
 // k_rows_to_columns: rows [0, nrows) of a [row][M] spectrum array become columns [c0 + r] of a [M][ldc] array; rows at or beyond
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         }
         __syncthreads();
         for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
-            const int b = e / 16, q = e % 16;
-            dst[(size_t) (b0 + b) * a.xt_len + r0 + q] = l_t[mfma_xt_pos(q)][b];
+            const int b = e / 16, q = e % 16, c = (q >> 1) & 1, t = mfma_xt_slot_block(q);
+            dst[(size_t) (b0 + b) * a.xt_len + r0 + q] = make_float2(mfma_component(l_t[t][b], c), mfma_component(l_t[t + 4][b], c));
         }
         return;
     }
@@ -150,16 +154,24 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         wave_split_forward<M>(lb, l_tw, lane, [&](int b, float2 v) { dst[b] = v; lb[b] = v; });
     }
     __syncthreads();
-    // Xt[s][bin][xt_hist + j0 .. + NBW), inside every segment of 16 blocks in mfma_xt_pos order: thread -> (bin, position p of the
-    // workgroup's blocks); consecutive threads write consecutive positions (whole 128-byte lines for NBW = 16)
+    // Xt[s][bin][xt_hist + j0 .. + NBW), inside every segment of 16 blocks in mfma_xt_float order: thread -> (bin, slot p of the
+    // workgroup's blocks); consecutive threads write consecutive slots (whole 128-byte lines for NBW = 16).  Blocks beyond the
+    // call's last one are not written (their waves transformed nothing).
     float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist;
+    const int t_end = a.t_first + a.t_count;
     for (int e = threadIdx.x; e < M * NBW; e += kWave * NBW) {
         const int bin = e / NBW, p = e % NBW;
-        if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: position j0 + p takes block mfma_xt_pos(j0 + p)
-            const int t = mfma_xt_pos(j0 + p);
-            if (t < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + j0 + p] = l_buf[t - j0][bin];
-        } else {                                       // part of a segment: block j0 + p goes to its (scattered) position
-            if (j0 + p < a.t_first + a.t_count) xt[(size_t) bin * a.xt_len + mfma_xt_pos(j0 + p)] = l_buf[p][bin];
+        if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: slot p takes one component of two of its blocks
+            const int c = (p >> 1) & 1, t = mfma_xt_slot_block(p);
+            float2 *dst = xt + (size_t) bin * a.xt_len + j0 + p;
+            if (j0 + t + 4 < t_end) *dst = make_float2(mfma_component(l_buf[t][bin], c), mfma_component(l_buf[t + 4][bin], c));
+            else if (j0 + t < t_end) reinterpret_cast<float *>(dst)[0] = mfma_component(l_buf[t][bin], c);
+        } else {                                       // part of a segment: the two components of block j0 + p go to their (scattered) floats
+            if (j0 + p < t_end) {
+                float *xf = reinterpret_cast<float *>(xt + (size_t) bin * a.xt_len);
+                xf[mfma_xt_float(j0 + p, 0)] = l_buf[p][bin].x;
+                xf[mfma_xt_float(j0 + p, 1)] = l_buf[p][bin].y;
+            }
         }
     }
 }
@@ -196,91 +208,113 @@ __device__ __forceinline__ float2 from_lane(int byte_addr, float2 v)
 }
 
 // The chunks [jb, je) of one wave: its bin of one tile.  PACKED = bin 0 (DC and Nyquist: two real products).
-//   x operand of chunk j, k group g, lane (n, kq):  block 256 tile + 16 (n - j) + 4 g + kq = Xt element x_elem0 + 16 (n - j) + 4 kq + g
+//   x operand of chunk j, k group g, lane (n, kq):  block 256 tile + 16 (n - j) + 4 g + kq = Xt floats of segment x_elem0 / 16 + n - j at 8 kq + g (re), + 4 (im)
 //   h operand                       lane (i, kq):  tap 16 j + i - 4 g - kq = Ht element 16 + that
+// A complex product is THREE real ones (Xr Hr, Xi Hi, (Xr + Xi)(Hr + Hi); re = first - second, im = third - first - second, formed
+// once after the loop from three accumulators): 12 MFMAs per chunk instead of 16.  The sums cost four v_pk_add_f32 per chunk.
+// (Rounding: the imaginary part now carries the error of three sums instead of two -- measured against the oracle in the tests,
+// the same tolerance.  A non-finite sample can turn into NaN where the four-product form gives Inf; see the header note.)
 // What a chunk fetches is what is NEW, once per wave, and the lanes share it among themselves -- the texture path (one per CU, 64 bytes
 // a clock) is the resource sixteen independent waves run out of first: with every lane loading its own operands (8 loads of 512
 // bytes per chunk, most of them the same few addresses) the kernel took 37 us at configs[1], with a window re-loaded from the L1
 // every chunk 44 us, against 30 us with no loads at all (tools/mfma_stamps.hip, profiles/r04_mfma_stamps.txt):
-//   * taps: the 31 a chunk touches (16 j - 15 .. 16 j + 15) are ONE 8-byte load by lanes 0 .. 31; lane (i, kq) then takes tap
+//   * taps: the 31 a chunk touches (16 j - 15 .. 16 j + 15) are ONE 8-byte load by lanes 0 .. 30; lane (i, kq) then takes tap
 //     i - kq - 4 g + 15 from that lane through ds_bpermute, four times (g) -- lane addresses that never change;
 //   * blocks: operand lane (n, kq) of chunk j + 1 holds what lane (n - 1, kq) held for chunk j, so a DPP row shift moves the window
-//     along and only the lanes n = 0 load: four lanes, 32 contiguous bytes each (mfma_xt_pos keeps a lane's four k groups together).
-// Two register sets swap roles every chunk (the loop is unrolled by two, nothing is copied): while one is multiplied, the other
-// receives the next chunk's taps and new blocks, issued one chunk of MFMAs before their use.
+//     along and only the lanes n = 0 load: four lanes, 32 contiguous bytes each (mfma_xt_float keeps a lane's four k groups together).
+// The lanes that have nothing to load carry a byte offset beyond the buffer (the descriptor's range check returns zeros without a
+// memory access): no exec-mask branches in the loop.  Every non-MFMA instruction takes matrix-pipe time from the other three waves
+// of the SIMD (ablation in profiles/NOTES.md), so the loop is exactly 12 MFMAs + 8 ds_bpermute + 8 DPP moves + 4 packed adds + 3 loads.
 template <bool PACKED>
 __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rh, int lane, int x_elem0, int jb, int je,
                                                v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i)
 {
     const int n = lane % kMfmaSeg, kq = lane / kMfmaSeg;
+    constexpr unsigned kNoLoad = 0x7ffffff0u;                              // a byte offset beyond every buffer: the lane's load returns zeros and fetches nothing
     const unsigned vx = (unsigned) (kMfmaSeg * n + 4 * kq) * 8u;           // the lane's four k groups in the window's first chunk
-    const unsigned vx_new = (unsigned) (4 * kq) * 8u;                      // ... in a chunk's new segment (lanes n = 0)
-    const unsigned vh = (unsigned) (min(lane, 30) + 1) * 8u;               // lane l < 31 loads tap 16 j - 15 + l (Ht element 16 j + 1 + l)
+    const unsigned vx_new = n == 0 ? (unsigned) (4 * kq) * 8u : kNoLoad;   // ... in a chunk's new segment (lanes n = 0)
+    const unsigned vh = lane < 31 ? (unsigned) (lane + 1) * 8u : kNoLoad;  // lane l < 31 loads tap 16 j - 15 + l (Ht element 16 j + 1 + l)
     int from[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) from[g] = (15 + n - kq - 4 * g) * 4;       // whose tap this lane multiplies with in k group g
     // scalar byte offsets of chunk j: its window starts 16 j blocks before the tile, its taps at 16 j
     auto sx = [&](int j) { return (unsigned) (x_elem0 - kMfmaSeg * j) * 8u; };
     auto sh = [&](int j) { return (unsigned) (kMfmaSeg * j) * 8u; };
-    struct Set { float2 x[4], h[4], taps; };
+    // operands of one chunk: k groups 0 .. 3 of the blocks (re, im, re + im) and of the taps; `taps` = what the lane loaded
+    struct Set { v4f_t xr, xi; v2f_t xs[2], hr[2], hi[2], hs[2]; float2 taps; };
     Set A, B;
-    auto load_taps = [&](Set &s, int j) { if (lane < 32) s.taps = buf_ld8<0>(rh, vh, sh(j)); };
-    auto load_new = [&](Set &s, int j) {                                   // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
-        if (n == 0) { buf_ld16<0>(rx, vx_new, sx(j), s.x[0], s.x[1]); buf_ld16<16>(rx, vx_new, sx(j), s.x[2], s.x[3]); }
+    auto load_taps = [&](Set &s, int j) { s.taps = buf_ld8<0>(rh, vh, sh(j)); };
+    auto load_x = [&](Set &s, unsigned v, int j) {                         // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
+        const v4u_t re = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j), 0), im = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j) + 16, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++) { s.xr[g] = __uint_as_float(re[g]); s.xi[g] = __uint_as_float(im[g]); }
     };
     auto spread_taps = [&](Set &s) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) s.h[g] = from_lane(from[g], s.taps);
+        for (int g = 0; g < 4; g++) {
+            const float2 t = from_lane(from[g], s.taps);
+            s.hr[g / 2][g % 2] = t.x; s.hi[g / 2][g % 2] = t.y;
+        }
+    };
+    auto sums = [&](Set &s) {                                              // four v_pk_add_f32
+        if constexpr (!PACKED) {
+            s.xs[0] = s.xr.lo + s.xi.lo; s.xs[1] = s.xr.hi + s.xi.hi;
+            s.hs[0] = s.hr[0] + s.hi[0]; s.hs[1] = s.hr[1] + s.hi[1];
+        }
     };
     auto multiply = [&](const Set &s) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(s.xr[g], s.hr[g / 2][g % 2], acc_r, 0, 0, 0);
             if constexpr (PACKED) {
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].x, acc_r, 0, 0, 0);
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].y, acc_i, 0, 0, 0);
-            } else {
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].x, acc_r, 0, 0, 0);
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].x, acc_i, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].y, s.h[g].y, acc_n, 0, 0, 0);      // subtracted at the end: no sign flip in the loop
-                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.x[g].x, s.h[g].y, acc_i, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.xi[g], s.hi[g / 2][g % 2], acc_i, 0, 0, 0);
+            } else {                                   // three real products per complex one: Xr Hr, Xi Hi, (Xr + Xi)(Hr + Hi); combined after the loop
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(s.xi[g], s.hi[g / 2][g % 2], acc_n, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_16x16x4f32(s.xs[g / 2][g % 2], s.hs[g / 2][g % 2], acc_i, 0, 0, 0);
             }
         }
     };
-    // chunk j is multiplied out of `cur`; `nxt` (its taps and new blocks loaded a chunk ago) becomes chunk j + 1's operands;
-    // `cur` is then reloaded for chunk j + 2
+    // Three register sets rotate (the loop is unrolled by three, nothing is copied): chunk j is multiplied out of `cur`; before
+    // that `nxt` (taps and new blocks loaded two chunks ago) starts to become chunk j + 1's operands -- the lane exchanges run
+    // under the MFMAs; `far` holds chunk j + 2's loads in flight; `cur` is then reloaded for chunk j + 3
     auto step = [&](int j, Set &cur, Set &nxt) {
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(cur);
         __builtin_amdgcn_sched_barrier(0);
         spread_taps(nxt);
 #pragma unroll
-        for (int g = 0; g < 4; g++) nxt.x[g] = make_float2(shift_in(nxt.x[g].x, cur.x[g].x), shift_in(nxt.x[g].y, cur.x[g].y));
+        for (int g = 0; g < 4; g++) { nxt.xr[g] = shift_in(nxt.xr[g], cur.xr[g]); nxt.xi[g] = shift_in(nxt.xi[g], cur.xi[g]); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(IRB_MFMA_EXP & 2)) { load_new(cur, j + 2); load_taps(cur, j + 2); }
+        multiply(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        sums(nxt);
+        if constexpr (!(IRB_MFMA_EXP & 2)) { load_x(cur, vx_new, j + 3); load_taps(cur, j + 3); }
     };
-    buf_ld16<0>(rx, vx, sx(jb), A.x[0], A.x[1]);                           // the whole window of the first chunk: every lane its own 32 bytes
-    buf_ld16<16>(rx, vx, sx(jb), A.x[2], A.x[3]);
-    A.taps = B.taps = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int g = 0; g < 4; g++) B.x[g] = make_float2(0.f, 0.f);
+    Set C;
+    load_x(A, vx, jb);                                                     // the whole window of the first chunk: every lane its own 32 bytes
     load_taps(A, jb);
-    load_new(B, jb + 1);
+    load_x(B, vx_new, jb + 1);
     load_taps(B, jb + 1);
+    load_x(C, vx_new, jb + 2);
+    load_taps(C, jb + 2);
     spread_taps(A);
+    sums(A);
     int j = jb;
 #pragma unroll 1
-    for (; j + 1 < je; j += 2) {
+    for (; j + 3 <= je; j += 3) {
         step(j, A, B);
-        step(j + 1, B, A);
+        step(j + 1, B, C);
+        step(j + 2, C, A);
     }
-    if (j < je) { __builtin_amdgcn_sched_barrier(0); multiply(A); }
+    if (j < je) {                                                          // one or two chunks left
+        step(j, A, B);
+        if (j + 1 < je) { __builtin_amdgcn_sched_barrier(0); multiply(B); }
+    }
 }
 
 // grid = S * tile_count * splits * (M / 16); block = 1024.  Partial spectra: part[s][t - t_base][split][M], part_T blocks per
 // stream (a call may be multiplied in two launches -- whole rounds of workgroups, then the remaining tiles with more partition
 // splits -- each with its own partial-spectrum region; see launch_tiled).
 template <int N>
-__global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cmac_mfma(StepArgs a)
+__global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
 {
     constexpr int M = N / 2;
     static_assert(M % kMfmaBins == 0, "bins per workgroup");
@@ -318,13 +352,19 @@ __global__ __launch_bounds__(kMfmaThreads) __attribute__((amdgpu_waves_per_eu(8,
     // LDS, so that each output row leaves as one whole 128-byte line
     const int i = lane % kMfmaSeg, kq = lane / kMfmaSeg;
 #pragma unroll
-    for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + i) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], acc_i[v]);
+    for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + i) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], bin == 0 ? acc_i[v] : acc_i[v] - acc_r[v] - acc_n[v]);
     __syncthreads();
     const int sbin = tid % kMfmaBins, srow = tid / kMfmaBins;
 #pragma unroll
     for (int it = 0; it < kMfmaTile / (kMfmaThreads / kMfmaBins); it++) {
         const int tl = srow + (kMfmaThreads / kMfmaBins) * it, t = kMfmaTile * tile + tl;
-        if (t < a.T) a.part[(((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin] = l_o[tl * kMfmaOS + sbin];
+        if constexpr (IRB_MFMA_EXP & 4) continue;
+        float2 *dst = a.part + (((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin;
+        const float2 val = l_o[tl * kMfmaOS + sbin];
+        if (t < a.T) {
+            if constexpr (IRB_MFMA_EXP & 8) { typedef float v2f_x __attribute__((ext_vector_type(2))); v2f_x q; q.x = val.x; q.y = val.y; __builtin_nontemporal_store(q, reinterpret_cast<v2f_x *>(dst)); }
+            else *dst = val;
+        }
     }
     IRB_STAMP(a, 7);
 }

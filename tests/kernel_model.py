@@ -221,11 +221,11 @@ def mfma_chunks(np_):
 
 
 def mfma_hist(P):
-    return MFMA_SEG * (mfma_chunks(P) + 2)
+    return MFMA_SEG * (mfma_chunks(P) + 3)
 
 
 def mfma_taps(P):
-    return MFMA_SEG * (mfma_chunks(P) + 3)
+    return MFMA_SEG * (mfma_chunks(P) + 4)
 
 
 def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
@@ -252,24 +252,37 @@ def mfma_plan(T, units, P, wgs=256, min_chunks=6, res=1):
     return out
 
 
-def mfma_xt_pos(t):
-    """position of block t inside its segment of 16 in Xt: [t % 4][t / 4 % 4] (a 4 x 4 transpose, its own inverse)"""
-    return (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3)
+def mfma_xt_float(t, c):
+    """float index of component c (0 re, 1 im) of block t in Xt: inside every segment of 16 blocks (32 floats) block 4 g + kq sits
+    at 8 kq + 4 c + g"""
+    return ((t & ~15) << 1) | ((t & 3) << 3) | (c << 2) | ((t >> 2) & 3)
+
+
+def mfma_xt_slot_block(p):
+    """the 8-byte slot p < 16 of a segment holds component (p >> 1) & 1 of this block of the segment and of that + 4"""
+    return ((p & 1) << 3) | (p >> 2)
 
 
 def mfma_layouts(X, H, T, P):
     """The operands as the kernels that produce them lay them out for ONE bin: Xt = [history | the call's blocks | zeros up to whole
-    tiles], every segment of 16 in mfma_xt_pos order (k_rows_to_columns<PERM> / irb_fdl_reset, k_push_fft_batch_t), Ht = [16 zeros |
-    taps | zeros] (k_rows_to_columns).  X: callable tau -> complex for tau in [-hist, T); H: the np taps in use (np <= P)."""
+    tiles] as FLOATS, every segment of 16 in mfma_xt_float order, written slot by slot the way k_push_fft_batch_t does (8-byte slot p
+    = one component of two blocks); Ht = [16 zeros | taps | zeros] (k_rows_to_columns).  X: callable tau -> complex for tau in
+    [-hist, T); H: the np taps in use (np <= P)."""
     hist, taps = mfma_hist(P), mfma_taps(P)
     Tpad = (T + MFMA_TILE - 1) // MFMA_TILE * MFMA_TILE
     lin = np.zeros(hist + Tpad, np.complex128)
     for tau in range(-hist, T):
         lin[hist + tau] = X(tau)
     lin[hist + T:] = 12345.0 + 6789.0j                 # what an earlier, longer call left behind: finite, must not matter
-    xt = np.zeros_like(lin)
-    for e in range(len(lin)):
-        xt[mfma_xt_pos(e)] = lin[e]                    # (hist is a multiple of 16: segments of the call and of the buffer coincide)
+    xt = np.full(2 * len(lin), np.nan)
+    for seg in range(0, len(lin), 16):                 # (hist is a multiple of 16: segments of the call and of the buffer coincide)
+        for p in range(16):
+            c, t = (p >> 1) & 1, mfma_xt_slot_block(p)
+            for k, blk in enumerate((t, t + 4)):
+                v = lin[seg + blk]
+                xt[2 * (seg + p) + k] = v.imag if c else v.real
+    for e in range(len(lin)):                          # the slot writer and the per-float formula (partial segments, N >= 1024) agree
+        assert xt[mfma_xt_float(e, 0)] == lin[e].real and xt[mfma_xt_float(e, 1)] == lin[e].imag
     ht = np.zeros(taps, np.complex128)
     ht[16:16 + len(H)] = H
     return xt, ht, hist
@@ -277,9 +290,10 @@ def mfma_layouts(X, H, T, P):
 
 def mfma_wave(xt, ht, hist, tile, jb, je):
     """mfma_chunk_run for one wave (one bin of one tile, chunks [jb, je)): byte offsets of the buffer loads (per-lane voffset, scalar
-    offset, immediate), which lanes load (the taps: lanes 0 .. 31, one 8-byte load; a chunk's new segment of blocks: the four lanes
-    n = 0, two 16-byte loads), ds_bpermute handing the taps to the lanes that multiply with them, the DPP row shift that moves
-    the X window along, the two register sets that swap roles, the MFMA's operand and result maps.  Returns O[n][i] (16 x 16)."""
+    offset, immediate), which lanes load (the taps: lanes 0 .. 30, one 8-byte load; a chunk's new segment of blocks: the four lanes
+    n = 0, two 16-byte loads: four real parts, four imaginary parts), ds_bpermute handing the taps to the lanes that multiply with
+    them, the DPP row shift that moves the X window along, the three register sets that rotate, the three real products of a
+    complex one, the MFMA's operand and result maps.  Returns O[n][i] (16 x 16)."""
     lanes = [(l % 16, l // 16) for l in range(64)]                 # (n or i, kq)
     x_elem0 = hist + MFMA_TILE * tile
     sx = lambda j: (x_elem0 - 16 * j) * 8
@@ -289,25 +303,27 @@ def mfma_wave(xt, ht, hist, tile, jb, je):
         assert byte % 8 == 0 and 0 <= byte // 8 < len(buf)          # nothing the kernel addresses is out of range
         return buf[byte // 8]
 
-    def ld32(byte):                                                 # two buffer_load_dwordx4 at immediates 0 and 16: the lane's four k groups
-        return [ld(xt, byte + 8 * g) for g in range(4)]
+    def ld32(byte):                                                 # two buffer_load_dwordx4: re of the lane's four k groups, then im
+        assert byte % 16 == 0 and 0 <= byte // 4 and byte // 4 + 8 <= len(xt)
+        f = xt[byte // 4: byte // 4 + 8]
+        return list(f[:4]), list(f[4:])
 
     class Set:
         def __init__(self):
-            self.x = [[0.0] * 64 for _ in range(4)]
+            self.xr = [[0.0] * 64 for _ in range(4)]
+            self.xi = [[0.0] * 64 for _ in range(4)]
             self.h = [[0.0] * 64 for _ in range(4)]
             self.taps = [0.0] * 64
 
-    def load_taps(s, j):                                            # lanes 0 .. 31: tap 16 j - 15 + l at Ht element 16 j + 1 + min(l, 30)
-        for l in range(32):
-            s.taps[l] = ld(ht, (min(l, 30) + 1) * 8 + sh(j))
+    def load_taps(s, j):                                            # lanes 0 .. 30: tap 16 j - 15 + l at Ht element 16 j + 1 + l; the others get zeros
+        for l in range(64):
+            s.taps[l] = ld(ht, (l + 1) * 8 + sh(j)) if l < 31 else 0.0
 
-    def load_new(s, j):                                             # lanes n = 0: their four k groups of the segment chunk j adds
+    def load_new(s, j):                                             # lanes n = 0: their four k groups of the segment chunk j adds; the others get zeros
         for l, (n, kq) in enumerate(lanes):
-            if n == 0:
-                v = ld32(4 * kq * 8 + sx(j))
-                for g in range(4):
-                    s.x[g][l] = v[g]
+            re, im = ld32(4 * kq * 8 + sx(j)) if n == 0 else ([0.0] * 4, [0.0] * 4)
+            for g in range(4):
+                s.xr[g][l], s.xi[g][l] = re[g], im[g]
 
     def spread_taps(s):                                             # ds_bpermute: lane (i, kq) takes the tap lane 15 + i - kq - 4 g holds
         for g in range(4):
@@ -318,41 +334,50 @@ def mfma_wave(xt, ht, hist, tile, jb, je):
 
     def shift(nxt, cur):                                            # v_mov_b32_dpp row_shr:1, bound_ctrl off: lanes n = 0 keep what they loaded
         for g in range(4):
-            nxt.x[g] = [nxt.x[g][l] if n == 0 else cur.x[g][l - 1] for l, (n, kq) in enumerate(lanes)]
+            nxt.xr[g] = [nxt.xr[g][l] if n == 0 else cur.xr[g][l - 1] for l, (n, kq) in enumerate(lanes)]
+            nxt.xi[g] = [nxt.xi[g][l] if n == 0 else cur.xi[g][l - 1] for l, (n, kq) in enumerate(lanes)]
 
-    acc = np.zeros((16, 16), np.complex128)
+    acc_r, acc_n, acc_s = np.zeros((16, 16)), np.zeros((16, 16)), np.zeros((16, 16))
 
     def multiply(s):
         for g in range(4):
             for l, (n, kq) in enumerate(lanes):                     # A operand lane (row n, k = kq), B operand lane (k = kq, column i)
                 for l2, (i, kq2) in enumerate(lanes):
                     if kq2 == kq:
-                        acc[n, i] += s.x[g][l] * s.h[g][l2]
+                        hr, hi = s.h[g][l2].real, s.h[g][l2].imag
+                        acc_r[n, i] += s.xr[g][l] * hr
+                        acc_n[n, i] += s.xi[g][l] * hi
+                        acc_s[n, i] += (s.xr[g][l] + s.xi[g][l]) * (hr + hi)
 
     def step(j, cur, nxt):
-        multiply(cur)
         spread_taps(nxt)
         shift(nxt, cur)
-        load_new(cur, j + 2)
-        load_taps(cur, j + 2)
+        multiply(cur)
+        load_new(cur, j + 3)
+        load_taps(cur, j + 3)
 
-    A, B = Set(), Set()
+    A, B, C = Set(), Set(), Set()
     for l, (n, kq) in enumerate(lanes):                             # the whole window of the first chunk: every lane its own 32 bytes
-        v = ld32((16 * n + 4 * kq) * 8 + sx(jb))
+        re, im = ld32((16 * n + 4 * kq) * 8 + sx(jb))
         for g in range(4):
-            A.x[g][l] = v[g]
+            A.xr[g][l], A.xi[g][l] = re[g], im[g]
     load_taps(A, jb)
     load_new(B, jb + 1)
     load_taps(B, jb + 1)
+    load_new(C, jb + 2)
+    load_taps(C, jb + 2)
     spread_taps(A)
     j = jb
-    while j + 1 < je:
+    while j + 3 <= je:
         step(j, A, B)
-        step(j + 1, B, A)
-        j += 2
+        step(j + 1, B, C)
+        step(j + 2, C, A)
+        j += 3
     if j < je:
-        multiply(A)
-    return acc
+        step(j, A, B)
+        if j + 1 < je:
+            multiply(B)
+    return (acc_r - acc_n) + 1j * (acc_s - acc_r - acc_n)
 
 
 def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
