@@ -66,6 +66,12 @@ __host__ __device__ constexpr int mfma_xt_float(int t, int c) { return ((t & ~15
 // the 8-byte slot p < 16 of a segment therefore holds component (p >> 1) & 1 of the blocks mfma_xt_slot_block(p) and that + 4
 __host__ __device__ constexpr int mfma_xt_slot_block(int p) { return ((p & 1) << 3) | (p >> 2); }
 __device__ __forceinline__ float mfma_component(const float2 &v, int c) { return c ? v.y : v.x; }
+// 8 bytes written through (non-temporal): rows the NEXT kernel reads once -- they leave during the kernel, not in its end-of-kernel write-back
+__device__ __forceinline__ void nt_store2(float2 *dst, float2 v)
+{
+    v2f_t q = {v.x, v.y};
+    __builtin_nontemporal_store(q, reinterpret_cast<v2f_t *>(dst));
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_rows_to_columns: rows [0, nrows) of a [row][M] spectrum array become columns [c0 + r] of a [M][ldc] array; rows at or beyond
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         float2 *dst = a.X + ((size_t) s * a.R + slot) * M;
         // the split reads bins b and M - b of the transform and writes the same two positions: in place, after all reads of the wave
         float2 *lb = l_buf[wave];
-        wave_split_forward<M>(lb, l_tw, lane, [&](int b, float2 v) { dst[b] = v; lb[b] = v; });
+        wave_split_forward<M>(lb, l_tw, lane, [&](int b, float2 v) { nt_store2(dst + b, v); lb[b] = v; });
     }
     __syncthreads();
     // Xt[s][bin][xt_hist + j0 .. + NBW), inside every segment of 16 blocks in mfma_xt_float order: thread -> (bin, slot p of the
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: slot p takes one component of two of its blocks
             const int c = (p >> 1) & 1, t = mfma_xt_slot_block(p);
             float2 *dst = xt + (size_t) bin * a.xt_len + j0 + p;
-            if (j0 + t + 4 < t_end) *dst = make_float2(mfma_component(l_buf[t][bin], c), mfma_component(l_buf[t + 4][bin], c));
+            if (j0 + t + 4 < t_end) nt_store2(dst, make_float2(mfma_component(l_buf[t][bin], c), mfma_component(l_buf[t + 4][bin], c)));
             else if (j0 + t < t_end) reinterpret_cast<float *>(dst)[0] = mfma_component(l_buf[t][bin], c);
         } else {                                       // part of a segment: the two components of block j0 + p go to their (scattered) floats
             if (j0 + p < t_end) {
@@ -227,7 +233,7 @@ __device__ __forceinline__ float2 from_lane(int byte_addr, float2 v)
 // of the SIMD (ablation in profiles/NOTES.md), so the loop is exactly 12 MFMAs + 8 ds_bpermute + 8 DPP moves + 4 packed adds + 3 loads.
 template <bool PACKED>
 __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rh, int lane, int x_elem0, int jb, int je,
-                                               v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i)
+                                               v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i, const StepArgs &a)
 {
     const int n = lane % kMfmaSeg, kq = lane / kMfmaSeg;
     constexpr unsigned kNoLoad = 0x7ffffff0u;                              // a byte offset beyond every buffer: the lane's load returns zeros and fetches nothing
@@ -297,6 +303,7 @@ __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdg
     load_taps(C, jb + 2);
     spread_taps(A);
     sums(A);
+    IRB_STAMP(a, 3);
     int j = jb;
 #pragma unroll 1
     for (; j + 3 <= je; j += 3) {
@@ -343,9 +350,10 @@ __global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
 #pragma unroll
     for (int v = 0; v < 4; v++) { acc_r[v] = 0.f; acc_n[v] = 0.f; acc_i[v] = 0.f; }
     const int x_elem0 = a.xt_hist + kMfmaTile * tile;              // Xt element of the tile's first block
+    IRB_STAMP(a, 1);
     if (jb < je) {
-        if (bin == 0) mfma_chunk_run<true>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i);
-        else          mfma_chunk_run<false>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i);
+        if (bin == 0) mfma_chunk_run<true>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
+        else          mfma_chunk_run<false>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
     }
     IRB_STAMP(a, 2);
     // ---- store: accumulator register v of lane (i, kq) is O[n = 4 kq + v][i], i.e. block 256 tile + 16 n + i of the call; through
@@ -354,16 +362,16 @@ __global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
 #pragma unroll
     for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + i) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], bin == 0 ? acc_i[v] : acc_i[v] - acc_r[v] - acc_n[v]);
     __syncthreads();
+    IRB_STAMP(a, 4);
     const int sbin = tid % kMfmaBins, srow = tid / kMfmaBins;
 #pragma unroll
     for (int it = 0; it < kMfmaTile / (kMfmaThreads / kMfmaBins); it++) {
         const int tl = srow + (kMfmaThreads / kMfmaBins) * it, t = kMfmaTile * tile + tl;
-        if constexpr (IRB_MFMA_EXP & 4) continue;
-        float2 *dst = a.part + (((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin;
-        const float2 val = l_o[tl * kMfmaOS + sbin];
+        // non-temporal: the rows are read once, by the next kernel -- written through now instead of by the end-of-kernel write-back (-0.8 us)
         if (t < a.T) {
-            if constexpr (IRB_MFMA_EXP & 8) { typedef float v2f_x __attribute__((ext_vector_type(2))); v2f_x q; q.x = val.x; q.y = val.y; __builtin_nontemporal_store(q, reinterpret_cast<v2f_x *>(dst)); }
-            else *dst = val;
+            const float2 val = l_o[tl * kMfmaOS + sbin];
+            v2f_t q = {val.x, val.y};
+            __builtin_nontemporal_store(q, reinterpret_cast<v2f_t *>(a.part + (((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin));
         }
     }
     IRB_STAMP(a, 7);

@@ -58,13 +58,14 @@ int main(int argc, char **argv)
     CK(hipMemcpy(st.data(), dst, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull, t1 = 0;
     for (int g = 0; g < grid; g++) { t0 = std::min(t0, st[g * 16 + 11]); t1 = std::max(t1, st[g * 16 + 12]); }
-    std::vector<double> start, dur, loop, store, clk;
+    std::vector<double> start, dur, loop, store, clk, ph[5];
     std::map<unsigned, int> per_cu;
     for (int g = 0; g < grid; g++) {
         const unsigned long long *t = &st[(size_t) g * 16];
         start.push_back((t[11] - t0) / 100.0);
         dur.push_back((t[12] - t[11]) / 100.0);
         loop.push_back((double) (t[2] - t[0]));
+        ph[0].push_back((double) (t[1] - t[0])); ph[1].push_back((double) (t[3] - t[1])); ph[2].push_back((double) (t[2] - t[3])); ph[3].push_back((double) (t[4] - t[2])); ph[4].push_back((double) (t[7] - t[4]));
         store.push_back((double) (t[7] - t[2]));
         clk.push_back((double) (t[7] - t[0]) / (double) (t[12] - t[11]) * 0.1);
         const unsigned hw = (unsigned) t[14], cu = ((unsigned) t[15] & 15u) << 16 | (hw & 0xFF00u) | ((hw >> 13) & 0x7u) << 4;
@@ -82,6 +83,8 @@ int main(int argc, char **argv)
     std::printf("  workgroup duration (us):               p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", pct(dur, .1), pct(dur, .5), pct(dur, .9), pct(dur, 1));
     std::printf("  first loads + chunk loop (wave 0, shader cycles): p10 %.0f  p50 %.0f  p90 %.0f  max %.0f   (<= %.0f MFMAs per wave: %.1f cycles each at p50; 128 = the matrix pipe's own time with four waves per SIMD)\n",
                 pct(loop, .1), pct(loop, .5), pct(loop, .9), pct(loop, 1), mfma_per_wave, pct(loop, .5) / mfma_per_wave);
+    std::printf("  phases of wave 0 at p50 (shader cycles): arguments + indices %.0f | first operands %.0f | chunk loop %.0f | wait for the other waves %.0f | stores %.0f\n",
+                pct(ph[0], .5), pct(ph[1], .5), pct(ph[2], .5), pct(ph[3], .5), pct(ph[4], .5));
     std::printf("  transpose + stores (shader cycles):    p10 %.0f  p50 %.0f  p90 %.0f  max %.0f\n", pct(store, .1), pct(store, .5), pct(store, .9), pct(store, 1));
     std::printf("  shader clock (GHz):                    p10 %.2f  p50 %.2f  p90 %.2f\n", pct(clk, .1), pct(clk, .5), pct(clk, .9));
     std::printf("  distinct CUs used %zu, most workgroups on one CU %d\n", per_cu.size(), maxper);
