@@ -139,7 +139,9 @@ int  irb_fdl_reset(irb_fdl *h);
  * Calls of several blocks multiply in tiles along the time axis (>= 512 blocks: on the
  * matrix cores) whose zero padding meets neighbouring blocks: for finite samples the
  * result is the reference's; an Inf or NaN sample can reach output blocks a tile's
- * width (<= 255 blocks) outside the np blocks it reaches in the reference.          */
+ * width (<= 255 blocks) outside the np blocks it reaches in the reference, and where
+ * the reference's four-product complex multiply gives Inf the matrix-core path (three
+ * real products: Xr Hr, Xi Hi, (Xr+Xi)(Hr+Hi)) can give NaN.                          */
 int  irb_fdl_process(irb_fdl *h, const float *const *in, float *const *out, int n_blocks);
 
 /* Replaces: the body of the IRCAP_IDLE branch for the n_blocks complete blocks of one host callback

@@ -219,7 +219,7 @@ __device__ __forceinline__ float2 from_lane(int byte_addr, float2 v)
 // A complex product is THREE real ones (Xr Hr, Xi Hi, (Xr + Xi)(Hr + Hi); re = first - second, im = third - first - second, formed
 // once after the loop from three accumulators): 12 MFMAs per chunk instead of 16.  The sums cost four v_pk_add_f32 per chunk.
 // (Rounding: the imaginary part now carries the error of three sums instead of two -- measured against the oracle in the tests,
-// the same tolerance.  A non-finite sample can turn into NaN where the four-product form gives Inf; see the header note.)
+// the same tolerance.  A non-finite sample can turn into NaN where the four-product form gives Inf: include/irb_fdl.h at irb_fdl_process.)
 // What a chunk fetches is what is NEW, once per wave, and the lanes share it among themselves -- the texture path (one per CU, 64 bytes
 // a clock) is the resource sixteen independent waves run out of first: with every lane loading its own operands (8 loads of 512
 // bytes per chunk, most of them the same few addresses) the kernel took 37 us at configs[1], with a window re-loaded from the L1

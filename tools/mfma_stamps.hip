@@ -14,6 +14,15 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+__global__ __launch_bounds__(1024) void k_null(unsigned long long *stamps)
+{
+    __shared__ float2 l_o[256 * 17];                   // the same LDS and thread footprint as k_cmac_mfma
+    if (threadIdx.x == 4000) l_o[0] = make_float2(0.f, 0.f);
+    unsigned long long r;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) :: "memory");
+    if (threadIdx.x == 0) stamps[blockIdx.x] = r;
+}
+
 int main(int argc, char **argv)
 {
     const int T = argc > 1 ? std::atoi(argv[1]) : 3750, splits = argc > 2 ? std::atoi(argv[2]) : 1, P = argc > 3 ? std::atoi(argv[3]) : 375;
@@ -54,6 +63,25 @@ int main(int argc, char **argv)
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    {   // what a launch of this shape costs with nothing in it: event to event, and first stamp to last
+        float nms = 0, best = 1e9f;
+        unsigned long long *dn;
+        CK(hipMalloc(&dn, (size_t) grid * sizeof(unsigned long long)));
+        for (int it = 0; it < 6; it++) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            k_null<<<dim3(grid), dim3(1024)>>>(dn);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&nms, e0, e1));
+            best = std::min(best, nms);
+        }
+        std::vector<unsigned long long> ns(grid);
+        CK(hipMemcpy(ns.data(), dn, ns.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::printf("empty kernel of the same grid / block / LDS: event time %.1f us (best of 6; last %.1f), first stamp -> last stamp %.1f us\n", best * 1e3, nms * 1e3,
+                    (*std::max_element(ns.begin(), ns.end()) - *std::min_element(ns.begin(), ns.end())) / 100.0);
+        CK(hipFree(dn));
     }
     CK(hipMemcpy(st.data(), dst, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull, t1 = 0;
