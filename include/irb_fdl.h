@@ -136,7 +136,7 @@ int  irb_fdl_reset(irb_fdl *h);
  * inverse FFT (:206; RT :504) and overlap-add (:209-213; RT :506-510).
  * in/out: host pointers, planar, one per stream (stream = instance*channels+ch),
  * n_blocks*block samples each; in[s]==out[s] is allowed.  Blocks until done.
- * Calls of several blocks multiply in tiles along the time axis (>= 512 blocks: on the
+ * Calls of several blocks multiply in tiles along the time axis (>= 256 blocks: on the
  * matrix cores) whose zero padding meets neighbouring blocks: for finite samples the
  * result is the reference's; an Inf or NaN sample can reach output blocks a tile's
  * width (<= 255 blocks) outside the np blocks it reaches in the reference, and where

@@ -62,7 +62,7 @@ struct irb_fdl {
     int tiled_kernel = 1;                    // time-tiled MAC: 1 k_cmac_tiled_pk (16 outputs x 8 partitions per step), 0 round 2's k_cmac_tiled<N,8> (IRB_TILED_KERNEL: A/B, tests)
     int tileTT = 16;                         // outputs per time tile of that kernel
     bool tile8_fused = true;                 // calls of <= 8 blocks with one workgroup per stream: one launch (k_tile8_fused; IRB_TILED_FUSED8=0: the three-launch form)
-    int mfma_min_T = 512;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
+    int mfma_min_T = 256;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
     int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
     int mfma_res = 1;                        // workgroups of it a CU holds at once (IRB_TILED_MFMA_RES)
@@ -269,7 +269,10 @@ int tiled_splits(const irb_fdl *h, int T)
 // long calls: the Toeplitz-block MAC on the matrix cores (fdl_mfma.hpp)
 bool use_mfma(const irb_fdl *h, int T)
 {
-    return h->mfma_capable && T >= h->mfma_min_T;        // (mfma_capable: gfx950, not stepwise, the handle's longest call qualifies; set at create)
+    // (mfma_capable: gfx950, not stepwise, the handle's longest call qualifies; set at create.)  The kernel multiplies whole tiles of 256
+    // blocks: a call that would pad by more than half (257 .. 341 blocks) stays on the packed-FMA kernel (profiles/r04_mfma_ab.txt)
+    const long padded = (long) (T + irb::kMfmaTile - 1) / irb::kMfmaTile * irb::kMfmaTile;
+    return h->mfma_capable && T >= h->mfma_min_T && (2 * padded <= 3 * (long) T || h->mfma_min_T < irb::kMfmaTile);   // (a threshold below one tile = a test forcing the path)
 }
 
 // How a call of T blocks is multiplied there.  A workgroup = one 256-block tile x 16 bins x one range of Toeplitz chunks and there
@@ -905,7 +908,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
     h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
     h->tile8_fused = env_int("IRB_TILED_FUSED8", 1) != 0;
-    h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 512));
+    h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 256));
     h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
     h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
     h->mfma_two_launch = env_int("IRB_TILED_MFMA_TWO_LAUNCH", 1) != 0;

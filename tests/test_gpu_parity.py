@@ -892,7 +892,7 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
                          ids=lambda v: str(v))
 def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
     """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_16x16x4_f32; the default for calls of
-    >= 512 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
+    >= 256 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
     that end inside the first 256-block tile or span several, partition counts around the 16-tap chunk edges (and 1, 2, 16 partitions:
     a single Toeplitz chunk, whose upper triangle is all padding), several partition splits (P = 600), packed bin 0, stereo IRs,
     history across calls (one signal as two calls)."""
@@ -940,11 +940,13 @@ def test_matrix_core_path_properties_at_the_full_baseline_size():
     assert rel_rms(ys[2], ys[0] + 2.0 * ys[1]) < 1e-6
 
 
-@pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513)], ids=lambda v: str(v))
+@pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513), (1, 1, 64, 3000, 256), (1, 2, 32, 2000, 390)],
+                         ids=lambda v: str(v))
 def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B, Lh, T):
-    """No tuning variable set: a call of >= 512 blocks multiplies on the matrix cores (another summation order than the packed-FMA
-    kernel's, so the two outputs differ in the last bits), shorter calls of the same engine do not; both against the oracle, and
-    one signal fed as a long and a short call continues seamlessly (the FDL history is shared by both kernels)."""
+    """No tuning variable set: a call of >= 256 blocks multiplies on the matrix cores (another summation order than the packed-FMA
+    kernel's, so the two outputs differ in the last bits) unless its last 256-block tile would be mostly padding (257 .. 341 blocks),
+    shorter calls of the same engine do not; both against the oracle, and one signal fed as a long and a short call continues
+    seamlessly (the FDL history is shared by both kernels)."""
     for k in ("IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS"):
         monkeypatch.delenv(k, raising=False)
     x = _streams(I, C, (T + 40) * B, 975)
@@ -956,6 +958,11 @@ def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B,
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
+            on_mfma = [eng.mac_kernel_name(t) == "k_cmac_mfma" for t in (T, 40, 255, 256, 257, 341, 342, 512)]
+            assert all(eng.mac_kernel_name(t).startswith(("k_cmac_mfma", "k_cmac_tiled_pk")) for t in (T, 40))
+            assert on_mfma[:2] == ([False, False] if off else [True, False])
+            if not off and T >= 512:               # (a call longer than the handle's longest is answered for the longest)
+                assert on_mfma[2:] == [False, True, False, False, True, True]
             outs.append(np.concatenate([eng.process(x[:, :T * B]), eng.process(x[:, T * B:])], axis=1))
     assert rel_rms(outs[0], outs[1]) < 2e-6
     assert not np.array_equal(outs[0][:, :T * B], outs[1][:, :T * B])          # the long call: two different kernels
