@@ -17,8 +17,6 @@
 
 namespace irb {
 
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-
 // H rows per IR set are a multiple of this (zero rows past the IR's partitions): one trip around the register ring of the
 // tile below (3 steps of 8 partitions), so a worker never needs a remainder loop
 constexpr int kTilePeriod = 24;

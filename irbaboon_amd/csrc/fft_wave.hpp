@@ -28,6 +28,64 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { /* a * conj(b) */ 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+// Packed fp32 (v_pk_*_f32: both halves of a 64-bit register pair in one instruction, the swizzles and sign flips of complex
+// arithmetic in the op_sel / neg modifiers): a lone wave issues one vector instruction per ~4-5 cycles whatever it does, so the
+// butterflies below are written in HALF the instructions of the scalar form (a complex product 2 instead of 4, a complex
+// add 1 instead of 2, a multiplication by +-i none at all).  Same roundings as the scalar fma sequence.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t pk(float2 a) { v2f_t r = {a.x, a.y}; return r; }
+__device__ __forceinline__ float2 unpk(v2f_t a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f_t lds_ld(const float2 *p) { return *reinterpret_cast<const v2f_t *>(p); }
+__device__ __forceinline__ void lds_st(float2 *p, v2f_t v) { *reinterpret_cast<v2f_t *>(p) = v; }
+// a * w
+__device__ __forceinline__ v2f_t pk_cmul(v2f_t a, v2f_t w)
+{
+    v2f_t t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                                   // (a.x w.x,  a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(t) : "v"(a), "v"(w));            // (-a.y w.y, a.y w.x) +
+    return t;
+}
+// a * conj(w)
+__device__ __forceinline__ v2f_t pk_cmulc(v2f_t a, v2f_t w)
+{
+    v2f_t t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                      // (a.x w.x, -a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(t) : "v"(a), "v"(w));                           // (a.y w.y,  a.y w.x) +
+    return t;
+}
+// a + (e.y, -e.x) = a - i e          and          a + (-e.y, e.x) = a + i e
+__device__ __forceinline__ v2f_t pk_add_mi(v2f_t a, v2f_t e)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(e));
+    return r;
+}
+__device__ __forceinline__ v2f_t pk_add_pi(v2f_t a, v2f_t e)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(e));
+    return r;
+}
+// a + conj(b), a - conj(b), conj(a - b)
+__device__ __forceinline__ v2f_t pk_add_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f_t pk_sub_conj(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f_t pk_conj_sub(v2f_t a, v2f_t b)
+{
+    v2f_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));                                      // (a.x - b.x, b.y - a.y)
+    return r;
+}
+
 // orders one wave's LDS traffic: everything before is complete and visible to the other lanes
 __device__ __forceinline__ void wave_sync()
 {
@@ -86,18 +144,18 @@ template <int M, int Ns, bool INV>
 __device__ __forceinline__ void radix4_stage(float2 *buf, const float2 *l_tw, int lane)
 {
     constexpr int N = 2 * M, B4 = M / 4, BPL = B4 > kWave ? B4 / kWave : 1, tstep = N / (4 * Ns);
-    float2 v[BPL][4], w[BPL][3];
+    v2f_t v[BPL][4], w[BPL][3];
 #pragma unroll
     for (int i = 0; i < BPL; i++) {
         const int j = lane + i * kWave;
         if (B4 >= kWave || j < B4) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[i][r] = buf[j + r * B4];
+            for (int r = 0; r < 4; r++) v[i][r] = lds_ld(buf + j + r * B4);
             if constexpr (Ns > 1) {
                 const int k = j & (Ns - 1);
-                w[i][0] = l_tw[k * tstep];
-                w[i][1] = l_tw[2 * k * tstep];
-                w[i][2] = l_tw[3 * k * tstep];            // < 3N/4: inside the extended table
+                w[i][0] = lds_ld(l_tw + k * tstep);
+                w[i][1] = lds_ld(l_tw + 2 * k * tstep);
+                w[i][2] = lds_ld(l_tw + 3 * k * tstep);   // < 3N/4: inside the extended table
             }
         }
     }
@@ -107,18 +165,17 @@ __device__ __forceinline__ void radix4_stage(float2 *buf, const float2 *l_tw, in
         const int j = lane + i * kWave;
         if (B4 >= kWave || j < B4) {
             const int k = j & (Ns - 1);
-            float2 v0 = v[i][0], v1 = v[i][1], v2 = v[i][2], v3 = v[i][3];
+            v2f_t v0 = v[i][0], v1 = v[i][1], v2 = v[i][2], v3 = v[i][3];
             if constexpr (Ns > 1) {
-                if (INV) { v1 = cmulc(v1, w[i][0]); v2 = cmulc(v2, w[i][1]); v3 = cmulc(v3, w[i][2]); }
-                else     { v1 = cmul(v1, w[i][0]);  v2 = cmul(v2, w[i][1]);  v3 = cmul(v3, w[i][2]); }
+                if (INV) { v1 = pk_cmulc(v1, w[i][0]); v2 = pk_cmulc(v2, w[i][1]); v3 = pk_cmulc(v3, w[i][2]); }
+                else     { v1 = pk_cmul(v1, w[i][0]);  v2 = pk_cmul(v2, w[i][1]);  v3 = pk_cmul(v3, w[i][2]); }
             }
-            const float2 s0 = cadd(v0, v2), d0 = csub(v0, v2), s1 = cadd(v1, v3), e = csub(v1, v3);
-            const float2 d1 = INV ? make_float2(-e.y, e.x) : make_float2(e.y, -e.x);   // (+i or -i) * e
+            const v2f_t s0 = v0 + v2, d0 = v0 - v2, s1 = v1 + v3, e = v1 - v3;
             const int j0 = 4 * j - 3 * k;
-            buf[j0]          = cadd(s0, s1);
-            buf[j0 + Ns]     = cadd(d0, d1);
-            buf[j0 + 2 * Ns] = csub(s0, s1);
-            buf[j0 + 3 * Ns] = csub(d0, d1);
+            lds_st(buf + j0, s0 + s1);
+            lds_st(buf + j0 + Ns, INV ? pk_add_pi(d0, e) : pk_add_mi(d0, e));         // d0 + (+i or -i) e
+            lds_st(buf + j0 + 2 * Ns, s0 - s1);
+            lds_st(buf + j0 + 3 * Ns, INV ? pk_add_mi(d0, e) : pk_add_pi(d0, e));     // d0 - (+i or -i) e
         }
     }
     wave_sync();
@@ -129,14 +186,14 @@ template <int M, bool INV>
 __device__ __forceinline__ void radix2_stage(float2 *buf, const float2 *l_tw, int lane)
 {
     constexpr int B2 = M / 2, BPL = B2 > kWave ? B2 / kWave : 1;
-    float2 v[BPL][2], w[BPL];
+    v2f_t v[BPL][2], w[BPL];
 #pragma unroll
     for (int i = 0; i < BPL; i++) {
         const int j = lane + i * kWave;
         if (B2 >= kWave || j < B2) {
-            v[i][0] = buf[j];
-            v[i][1] = buf[j + B2];
-            w[i] = l_tw[2 * j];                           // W_N^(2j) = W_M^j, j < M/2
+            v[i][0] = lds_ld(buf + j);
+            v[i][1] = lds_ld(buf + j + B2);
+            w[i] = lds_ld(l_tw + 2 * j);                  // W_N^(2j) = W_M^j, j < M/2
         }
     }
     wave_sync();
@@ -144,9 +201,9 @@ __device__ __forceinline__ void radix2_stage(float2 *buf, const float2 *l_tw, in
     for (int i = 0; i < BPL; i++) {
         const int j = lane + i * kWave;
         if (B2 >= kWave || j < B2) {
-            const float2 v1 = INV ? cmulc(v[i][1], w[i]) : cmul(v[i][1], w[i]);
-            buf[j]      = cadd(v[i][0], v1);
-            buf[j + B2] = csub(v[i][0], v1);
+            const v2f_t v1 = INV ? pk_cmulc(v[i][1], w[i]) : pk_cmul(v[i][1], w[i]);
+            lds_st(buf + j, v[i][0] + v1);
+            lds_st(buf + j + B2, v[i][0] - v1);
         }
     }
     wave_sync();
@@ -214,18 +271,19 @@ template <int M, typename Store>
 __device__ __forceinline__ void wave_split_forward(const float2 *Z, const float2 *l_tw, int lane, Store store)
 {
     constexpr int H = M / 2, I = H > kWave ? H / kWave : 1;
-    float2 p[I], q[I], w[I];
+    v2f_t p[I], q[I], w[I];
 #pragma unroll
     for (int i = 0; i < I; i++) {
         const int b = lane + i * kWave;
         if (H >= kWave || b < H) {
-            p[i] = Z[b];
-            q[i] = Z[(M - b) & (M - 1)];
-            w[i] = l_tw[b];
+            p[i] = lds_ld(Z + b);
+            q[i] = lds_ld(Z + ((M - b) & (M - 1)));
+            w[i] = lds_ld(l_tw + b);
         }
     }
     const float2 zh = Z[H];
     wave_sync();
+    const v2f_t half = {0.5f, 0.5f};
 #pragma unroll
     for (int i = 0; i < I; i++) {
         const int b = lane + i * kWave;
@@ -234,11 +292,13 @@ __device__ __forceinline__ void wave_split_forward(const float2 *Z, const float2
                 store(0, make_float2(p[i].x + p[i].y, p[i].x - p[i].y));
                 store(H, make_float2(zh.x, -zh.y));
             } else {
-                const float2 e = make_float2(0.5f * (p[i].x + q[i].x), 0.5f * (p[i].y - q[i].y));      // (p + conj q)/2
-                const float2 o = make_float2(0.5f * (p[i].y + q[i].y), -0.5f * (p[i].x - q[i].x));     // (p - conj q)/(2i)
-                const float2 t = cmul(w[i], o);
-                store(b, cadd(e, t));
-                store(M - b, make_float2(e.x - t.x, t.y - e.y));                                       // conj(e - t)
+                const v2f_t e = pk_add_conj(p[i], q[i]) * half;                // (p + conj q) / 2
+                const v2f_t d = pk_sub_conj(p[i], q[i]) * half;                // (p - conj q) / 2;  o = -i d
+                v2f_t t;                                                       // t = w o = (w.x d.y + w.y d.x,  w.y d.y - w.x d.x)
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(w[i]), "v"(d));       // (w.x d.y, -w.x d.x)
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(t) : "v"(w[i]), "v"(d));            // (w.y d.x,  w.y d.y) +
+                store(b, unpk(e + t));
+                store(M - b, unpk(pk_conj_sub(e, t)));                         // conj(e - t)
             }
         }
     }
@@ -250,14 +310,14 @@ template <int M>
 __device__ __forceinline__ void wave_split_inverse(float2 *Y, const float2 *l_tw, int lane)
 {
     constexpr int H = M / 2, I = H > kWave ? H / kWave : 1;
-    float2 p[I], q[I], w[I];
+    v2f_t p[I], q[I], w[I];
 #pragma unroll
     for (int i = 0; i < I; i++) {
         const int b = lane + i * kWave;
         if (H >= kWave || b < H) {
-            p[i] = Y[b];
-            q[i] = Y[(M - b) & (M - 1)];
-            w[i] = l_tw[b];
+            p[i] = lds_ld(Y + b);
+            q[i] = lds_ld(Y + ((M - b) & (M - 1)));
+            w[i] = lds_ld(l_tw + b);
         }
     }
     const float2 zh = Y[H];
@@ -270,11 +330,13 @@ __device__ __forceinline__ void wave_split_inverse(float2 *Y, const float2 *l_tw
                 Y[0] = make_float2(p[i].x + p[i].y, p[i].x - p[i].y);
                 Y[H] = make_float2(2.0f * zh.x, -2.0f * zh.y);
             } else {
-                const float2 e = make_float2(p[i].x + q[i].x, p[i].y - q[i].y);        // p + conj q
-                const float2 d = make_float2(p[i].x - q[i].x, p[i].y + q[i].y);        // p - conj q
-                const float2 o = cmulc(d, w[i]);                                       // * W_N^{-b}
-                Y[b] = make_float2(e.x - o.y, e.y + o.x);                              // e + i*o
-                Y[M - b] = make_float2(e.x + o.y, o.x - e.y);                          // conj(e) + i*conj(o)
+                const v2f_t e = pk_add_conj(p[i], q[i]);                       // p + conj q
+                const v2f_t d = pk_sub_conj(p[i], q[i]);                       // p - conj q
+                const v2f_t o = pk_cmulc(d, w[i]);                             // * W_N^{-b}
+                lds_st(Y + b, pk_add_pi(e, o));                                // e + i o
+                v2f_t r;                                                       // conj(e) + i conj(o) = (e.x + o.y, o.x - e.y)
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(e), "v"(o));
+                lds_st(Y + (M - b), r);
             }
         }
     }
