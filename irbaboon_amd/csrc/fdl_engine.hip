@@ -67,6 +67,7 @@ struct irb_fdl {
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
     int mfma_res = 1;                        // workgroups of it a CU holds at once (IRB_TILED_MFMA_RES)
     bool mfma_two_launch = true;             // whole rounds of workgroups + a second launch for the remaining tiles (IRB_TILED_MFMA_TWO_LAUNCH)
+    bool mfma_one_grid = true;               // ... both carried by one grid (IRB_TILED_MFMA_ONE_GRID)
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
@@ -323,6 +324,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.ovl_next = a.ovl; a.T = 1; a.nq = 1;
     a.Xt = h->d_Xt; a.Ht = h->d_Ht; a.xt_len = h->xt_len; a.xt_hist = h->xt_hist; a.ht_len = h->ht_len; a.hist_first = -1;
     a.tile_first = 0; a.tile_count = 1; a.t_base = 0; a.part_T = 1;
+    a.mf_wgs0 = 0; a.mf2_tile_first = 0; a.mf2_tile_count = 1; a.mf2_splits = 1; a.mf2_t_base = 0; a.mf2_part_T = 1; a.mf2_part_off = 0;
     a.t_first = 0; a.t_count = 1;
     for (int r = 0; r < 3; r++) a.reg_t0[r] = r == 0 ? 0 : 1;
     for (int r = 0; r < 2; r++) { a.reg_nq[r] = 1; a.reg_off[r] = 0; }
@@ -479,12 +481,27 @@ int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launch
         const int groups = h->M / irb::kMfmaBins;
         float2 *const part0 = a.part;
         h->n_launches--;
-        for (int i = first_launch; i < std::min(c.plan.n, first_launch + n_launches); i++) {
-            const MfmaLaunch &l = c.plan.l[i];
+        auto wgs = [&](const MfmaLaunch &l) { return h->S * l.tile_count * l.splits * groups; };
+        if (h->mfma_one_grid && first_launch == 0 && n_launches >= 2 && c.plan.n == 2) {
+            // both launches of the plan in ONE grid: the second's workgroups (few, short) come last in dispatch order and run on
+            // the CUs the first round frees -- one launch's fixed cost instead of two
+            const MfmaLaunch &l0 = c.plan.l[0], &l1 = c.plan.l[1];
             h->n_launches++;
-            a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
-            a.t_base = a.reg_t0[i]; a.part_T = a.reg_t0[i + 1] - a.reg_t0[i]; a.part = part0 + a.reg_off[i];
-            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(h->S * l.tile_count * l.splits * groups), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+            a.tile_first = l0.tile_first; a.tile_count = l0.tile_count; a.splits = l0.splits; a.nq = l0.splits;
+            a.t_base = a.reg_t0[0]; a.part_T = a.reg_t0[1] - a.reg_t0[0]; a.part = part0 + a.reg_off[0];
+            a.mf_wgs0 = wgs(l0);
+            a.mf2_tile_first = l1.tile_first; a.mf2_tile_count = l1.tile_count; a.mf2_splits = l1.splits;
+            a.mf2_t_base = a.reg_t0[1]; a.mf2_part_T = a.reg_t0[2] - a.reg_t0[1]; a.mf2_part_off = (long) a.reg_off[1] - (long) a.reg_off[0];
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l0) + wgs(l1)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        } else {
+            for (int i = first_launch; i < std::min(c.plan.n, first_launch + n_launches); i++) {
+                const MfmaLaunch &l = c.plan.l[i];
+                h->n_launches++;
+                a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
+                a.t_base = a.reg_t0[i]; a.part_T = a.reg_t0[i + 1] - a.reg_t0[i]; a.part = part0 + a.reg_off[i];
+                a.mf_wgs0 = 0;
+                FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+            }
         }
     }
     else if (c.one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
@@ -912,6 +929,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
     h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
     h->mfma_two_launch = env_int("IRB_TILED_MFMA_TWO_LAUNCH", 1) != 0;
+    h->mfma_one_grid = env_int("IRB_TILED_MFMA_ONE_GRID", 1) != 0;
     h->mfma_res = std::max(1, std::min(2, env_int("IRB_TILED_MFMA_RES", 1)));       // measured (profiles/r04_mfma_stamps.txt): two per CU start late and multiply slower
     // gfx950 only: the instruction timings and the DPP / buffer-load forms the kernel is written in are that chip's
     h->mfma_capable = h->is_gfx950 && !h->stepwise && h->mfma_min_T > 0 && h->Tmax >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;

@@ -72,6 +72,10 @@ struct StepArgs {
     int           hist_first;   // >= 0: k_push_fft_batch_t also rebuilds Xt's history columns from the ring, starting at this ring row
     int           tile_first, tile_count;   // the 256-block tiles this launch multiplies (a call may take two launches) ...
     int           t_base, part_T;           // ... and where its partial spectra go: part[s][t - t_base][nq][M], part_T blocks per stream
+    int           mf_wgs0;                  // > 0: ONE k_cmac_mfma grid carries both launches of a call's plan -- workgroups [0, mf_wgs0) are the
+                                            // first (tile_first, tile_count, splits, t_base, part_T, part), the rest the second:
+    int           mf2_tile_first, mf2_tile_count, mf2_splits, mf2_t_base, mf2_part_T;
+    long          mf2_part_off;             // its partial-spectrum region starts at part + mf2_part_off
     // batched FFT kernels: the blocks [t_first, t_first + t_count) of the call (irb_convolve_periodic moves a call's blocks in and out in chunks)
     int           t_first, t_count;
     // k_ifft_ola_run: where the partial spectra of a block are.  A matrix-core call's multiply may run as two launches (whole rounds of

@@ -327,13 +327,21 @@ __global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
     static_assert(M % kMfmaBins == 0, "bins per workgroup");
     constexpr int GROUPS = M / kMfmaBins;
     __shared__ float2 l_o[kMfmaTile * kMfmaOS];
-    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);       // the bin groups and splits of one tile share an XCD's L2 (the same FDL lines)
-    const int bg = wg % GROUPS, split = (wg / GROUPS) % a.splits, tile = a.tile_first + (wg / (GROUPS * a.splits)) % a.tile_count,
-              s = wg / (GROUPS * a.splits * a.tile_count);
+    // one grid may carry both launches of a call's plan (whole rounds of workgroups, then the remaining tiles with their partitions
+    // split): the second region's workgroups are the LAST in dispatch order, short, and start as the first region's CUs free up
+    const bool second = a.mf_wgs0 > 0 && (int) blockIdx.x >= a.mf_wgs0;
+    const int tile_first = second ? a.mf2_tile_first : a.tile_first, tile_count = second ? a.mf2_tile_count : a.tile_count,
+              splits = second ? a.mf2_splits : a.splits, t_base = second ? a.mf2_t_base : a.t_base, part_T = second ? a.mf2_part_T : a.part_T;
+    float2 *const part = second ? a.part + a.mf2_part_off : a.part;
+    const int first_wgs = a.mf_wgs0 > 0 ? min(a.mf_wgs0, (int) gridDim.x) : (int) gridDim.x;
+    // the bin groups and splits of one tile share an XCD's L2 (the same FDL lines)
+    const int wg = second ? xcd_contiguous_id(blockIdx.x - a.mf_wgs0, gridDim.x - a.mf_wgs0) : xcd_contiguous_id(blockIdx.x, first_wgs);
+    const int bg = wg % GROUPS, split = (wg / GROUPS) % splits, tile = tile_first + (wg / (GROUPS * splits)) % tile_count,
+              s = wg / (GROUPS * splits * tile_count);
     const int2 si = a.stream_info[s];
     const int set = si.x, np = si.y;
     const int J = mfma_chunks(np);
-    const int jb = (int) ((long) J * split / a.splits), je = (int) ((long) J * (split + 1) / a.splits);
+    const int jb = (int) ((long) J * split / splits), je = (int) ((long) J * (split + 1) / splits);
     const int b0 = bg * kMfmaBins;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
     IRB_STAMP(a, 0);
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
         if (t < a.T) {
             const float2 val = l_o[tl * kMfmaOS + sbin];
             v2f_t q = {val.x, val.y};
-            __builtin_nontemporal_store(q, reinterpret_cast<v2f_t *>(a.part + (((size_t) s * a.part_T + (t - a.t_base)) * a.nq + split) * M + b0 + sbin));
+            __builtin_nontemporal_store(q, reinterpret_cast<v2f_t *>(part + (((size_t) s * part_T + (t - t_base)) * splits + split) * M + b0 + sbin));
         }
     }
     IRB_STAMP(a, 7);

@@ -940,6 +940,29 @@ def test_matrix_core_path_properties_at_the_full_baseline_size():
     assert rel_rms(ys[2], ys[0] + 2.0 * ys[1]) < 1e-6
 
 
+def test_matrix_core_plan_of_two_regions_in_one_grid(monkeypatch):
+    """A call whose tiles do not fill whole rounds of workgroups is multiplied as two regions (the full rounds unsplit, the remaining
+    tiles with their partitions split; fdl_engine.hip: mfma_plan).  By default ONE k_cmac_mfma grid carries both (the second region's
+    workgroups last in dispatch order); IRB_TILED_MFMA_ONE_GRID=0 launches them one after the other.  Same arithmetic either way:
+    bit-identical outputs, one launch fewer, and the oracle's result.  (8 workgroups per round here, so 5 tiles = 4 + 1.)"""
+    I, C, B, Lh, T = 1, 1, 32, 100 * 32, 1280
+    x = _streams(I, C, T * B, 4242)
+    h = decaying_ir(4243, Lh)[None]
+    monkeypatch.setenv("IRB_TILED_MFMA_WGS", "8")
+    outs, launches = [], []
+    for one in ("1", "0"):
+        monkeypatch.setenv("IRB_TILED_MFMA_ONE_GRID", one)
+        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+            eng.set_ir(0, h)
+            assert eng.mac_kernel_name(T) == "k_cmac_mfma"
+            n0 = eng.counters()[0]
+            outs.append(eng.process(x))
+            launches.append(eng.counters()[0] - n0)
+    assert np.array_equal(outs[0], outs[1]) and launches[1] == launches[0] + 1
+    ref, _ = oracle.convolve_periodic(x, h, B)
+    assert rel_rms(outs[0][0], ref[0, :T * B]) < RMS_TOL
+
+
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513), (1, 1, 64, 3000, 256), (1, 2, 32, 2000, 390)],
                          ids=lambda v: str(v))
 def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B, Lh, T):
