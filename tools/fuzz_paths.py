@@ -35,9 +35,10 @@ while time.time() - t0 < budget:
     env["IRB_TILED_MFMA_MIN_CHUNKS"] = str(rng.choice([1, 6]))
     env["IRB_TILED_MFMA_TWO_LAUNCH"] = str(rng.choice([0, 1, 1]))   # whole rounds + remainder launch of the matrix-core MAC
     env["IRB_TILED_MFMA_RES"] = str(rng.choice([1, 1, 2]))
+    env["IRB_TILED_MFMA_ONE_GRID"] = str(rng.choice([0, 1, 1]))    # both regions of a plan in one grid / two launches
     env["IRB_TILED_FUSED8"] = str(rng.choice([0, 1, 1]))            # calls of <= 8 blocks as one launch / three
     for k in ("IRB_COLW", "IRB_COLS_HANDOFF", "IRB_PSPLITS", "IRB_TILED_KERNEL", "IRB_FUSED_U", "IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS",
-              "IRB_TILED_MFMA_TWO_LAUNCH", "IRB_TILED_MFMA_RES", "IRB_TILED_FUSED8", "IRB_OFFLINE_DIRECT", "IRB_OFFLINE_MAX_BLOCKS", "IRB_OFFLINE_CHUNK", "IRB_OFFLINE_HELPER"):
+              "IRB_TILED_MFMA_TWO_LAUNCH", "IRB_TILED_MFMA_RES", "IRB_TILED_MFMA_ONE_GRID", "IRB_TILED_FUSED8", "IRB_OFFLINE_DIRECT", "IRB_OFFLINE_MAX_BLOCKS", "IRB_OFFLINE_CHUNK", "IRB_OFFLINE_HELPER"):
         os.environ.pop(k, None)
     os.environ.update(env)
     if n % 4 == 3:
