@@ -406,3 +406,22 @@ def mfma_time_axis(X, H, T, P=None, units=16, wgs=256):
         r = 1 if t >= t0[1] else 0                                  # k_ifft_ola_run's look-up
         out[t] = parts[r][t - t0[r]].sum()
     return out
+
+
+def xcd_contiguous(bid, nwg):
+    """fdl_kernels.hpp: xcd_contiguous_id -- workgroup bid runs on XCD bid % 8; the ids of one XCD become a contiguous range"""
+    q, r, xcd, local = nwg >> 3, nwg & 7, bid & 7, bid >> 3
+    return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + local
+
+
+def mfma_one_grid_decode(block_idx, grid, plan, S, groups):
+    """k_cmac_mfma's first lines when ONE grid carries both launches of a plan: workgroups [0, wgs0) are the first region, the rest
+    (last in dispatch order) the second; each region decodes (bin group, split, tile, stream) from its own XCD-contiguous id.
+    plan = [(tile_first, tile_count, splits), ...] (one or two entries).  Returns (region, stream, tile, split, bin group)."""
+    wgs0 = S * plan[0][1] * plan[0][2] * groups
+    second = len(plan) == 2 and block_idx >= wgs0
+    tile_first, tile_count, splits = plan[1] if second else plan[0]
+    wg = xcd_contiguous(block_idx - wgs0, grid - wgs0) if second else xcd_contiguous(block_idx, wgs0 if len(plan) == 2 else grid)
+    return (1 if second else 0, wg // (groups * splits * tile_count), tile_first + (wg // (groups * splits)) % tile_count,
+            (wg // groups) % splits, wg % groups)
+

@@ -79,3 +79,22 @@ def test_toeplitz_block_time_axis(np_, P, T, units, wgs):
     assert hist >= np_ - 1                                   # the history columns hold every block an output can depend on
     plan = mfma_plan(T, units, P, wgs)
     assert sum(l[1] for l in plan) == (T + 255) // 256 and all(a[0] + a[1] == b[0] for a, b in zip(plan, plan[1:]))     # the launches tile the call
+
+
+@pytest.mark.parametrize("T,S,groups,P,wgs", [(4125, 1, 16, 375, 256), (1280, 1, 2, 100, 8), (5000, 2, 8, 3750, 256), (3750, 1, 16, 375, 256), (700, 3, 4, 60, 64)])
+def test_one_grid_carries_both_regions(T, S, groups, P, wgs):
+    """fdl_mfma.hpp / fdl_engine.hip (tiled_mac): the workgroups of a two-region plan in one grid -- every (region, stream, tile, split,
+    bin group) is decoded by exactly one workgroup, and the second region's workgroups are the last ones dispatched."""
+    from kernel_model import mfma_one_grid_decode, mfma_plan
+    plan = mfma_plan(T, S * groups, P, wgs)
+    sizes = [S * l[1] * l[2] * groups for l in plan]
+    grid = sum(sizes)
+    seen = {}
+    for b in range(grid):
+        key = mfma_one_grid_decode(b, grid, plan, S, groups)
+        assert key not in seen
+        seen[key] = b
+        assert key[0] == (1 if len(plan) == 2 and b >= sizes[0] else 0)
+    want = {(r, s, t, q, g) for r, l in enumerate(plan) for s in range(S) for t in range(l[0], l[0] + l[1]) for q in range(l[2]) for g in range(groups)}
+    assert set(seen) == want
+
