@@ -62,7 +62,11 @@ while time.time() - t0 < budget:
             den = np.sqrt(np.mean(ref[:nw] ** 2))
             err = np.sqrt(np.mean((yo[c, :nw] - ref[:nw]) ** 2)) / den if den > 0 else np.abs(yo[c, :nw]).max()
             worst = max(worst, err)
-            assert err < 1e-5 and not yo[c, nw:].any(), ("one-shot", Bo, Ca, Ci, La, Lho, keep, oenv, err)
+            if not (err < 1e-5 and not yo[c, nw:].any()):              # which blocks are wrong (a failure here has been seen once in ~90 000 calls and not reproduced)
+                d = np.abs(yo[c, :nw].astype(np.float64) - ref[:nw])
+                blocks = [(j, float(d[j * Bo:(j + 1) * Bo].max())) for j in range((nw + Bo - 1) // Bo)]
+                raise AssertionError(("one-shot", n, Bo, Ca, Ci, La, Lho, keep, oenv, env, err, "channel", c, "peak", float(np.abs(ref).max()),
+                                      "blocks off by > 1e-3 of it", [(j, round(v, 5)) for j, v in blocks if v > 1e-3 * np.abs(ref).max()][:40]))
         _lib.lib().irb_release_cached_plans()
         counts["one-shot"] = counts.get("one-shot", 0) + 1
     ir_ch = int(rng.integers(1, 3))
