@@ -21,10 +21,11 @@
 //     Ht[set][bin][16 + m]           the IR spectra with the tap index contiguous per bin, 16 zero taps in front, zeros behind
 //                                    (k_rows_to_columns at irb_fdl_set_ir*)
 // A wave owns ONE bin of one tile of 256 output blocks and one range of chunks, and nothing it reads is shared with another
-// wave through LDS memory.  Per chunk it issues 16 MFMAs, THREE small loads (one of the chunk's 31 taps by half the lanes, two of 16
-// bytes by the four lanes that start a new segment of the X window), 8 ds_bpermute that hand the taps to the lanes that multiply with
-// them, and 8 DPP moves that shift the X window by one segment -- see mfma_chunk_run.  The row step of a load sits in an SGPR, the
-// constant part in the instruction's immediate offset; ~60 VGPRs.  The only LDS memory and the only barrier are at the end: the
+// wave through LDS memory.  Per chunk it issues 12 MFMAs (a complex product as three real ones), THREE small loads (one of the chunk's
+// 31 taps by half the lanes, two of 16 bytes by the four lanes that start a new segment of the X window), 8 ds_bpermute that hand
+// the taps to the lanes that multiply with them, 8 DPP moves that shift the X window by one segment and 4 packed adds -- see
+// mfma_chunk_run.  The row step of a load sits in an SGPR; ~110 VGPRs (one workgroup of 16 waves per CU).  The only LDS memory and
+// the only barrier are at the end: the
 // 256 x 16 results of the sixteen waves (bins) of a workgroup are transposed so that each partial-spectrum row leaves as one whole
 // 128-byte line (part[s][t][split][M], summed over splits by k_ifft_ola_run).
 //
