@@ -30,7 +30,7 @@ while time.time() - t0 < budget:
         env = {"IRB_COLW": str(rng.choice([4, 16, 64])), "IRB_COLS_HANDOFF": str(rng.choice([0, 1, 2])), "IRB_PSPLITS": str(rng.integers(1, 17))}
     env["IRB_TILED_KERNEL"] = str(rng.choice([0, 1, 1]))        # round 2's tiled MAC / the packed-FMA one
     env["IRB_FUSED_U"] = str(rng.choice([2, 4]))
-    env["IRB_TILED_MFMA_MIN_T"] = str(rng.choice([0, 2, 2]))    # off / the matrix-core tiled MAC for every call of >= 2 blocks
+    env["IRB_TILED_MFMA_MIN_T"] = str(rng.choice([0, 2, 2, 256]))    # off / the matrix-core tiled MAC for every call of >= 2 blocks / the default rule
     env["IRB_TILED_MFMA_WGS"] = str(rng.choice([16, 256, 2048]))
     env["IRB_TILED_MFMA_MIN_CHUNKS"] = str(rng.choice([1, 6]))
     env["IRB_TILED_MFMA_TWO_LAUNCH"] = str(rng.choice([0, 1, 1]))   # whole rounds + remainder launch of the matrix-core MAC
