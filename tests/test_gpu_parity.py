@@ -186,6 +186,38 @@ def test_convolve_periodic_on_awkward_caller_memory():
     lib.irb_release_cached_plans()
 
 
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["direct", "staged"])
+def test_convolve_periodic_writes_every_sample_of_the_result(monkeypatch, direct):
+    """The Python mirror hands the library an UNINITIALISED result array (np.empty): every sample the call produces must be
+    written by it and the reference's dropped tail must be zeroed by it (fp/convolution.cpp:225-227,236-238).  Result buffers
+    poisoned beforehand, ragged and block-aligned lengths, both tail modes, one and several pieces, both forms."""
+    lib = _lib.lib()
+    monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+    poison = np.float32(1e30)
+    for k, (B, Ca, Ci, La, Lh, pieces) in enumerate([(256, 2, 2, 35656, 6168, 0), (64, 1, 2, 64 * 40, 64 * 3, 0), (128, 2, 1, 5001, 1, 0), (32, 1, 1, 7, 900, 0),
+                                                     (100, 2, 2, 12345, 777, 40), (16, 1, 1, 16 * 300 + 5, 16 * 20, 5)]):
+        if pieces:
+            monkeypatch.setenv("IRB_OFFLINE_MAX_BLOCKS", str(pieces))
+        else:
+            monkeypatch.delenv("IRB_OFFLINE_MAX_BLOCKS", raising=False)
+        x = np.stack([white_noise(7900 + 10 * k + c, La) for c in range(Ca)])
+        h = np.stack([decaying_ir(7950 + 10 * k + c, Lh) for c in range(Ci)])
+        for keep in (1, 0):
+            out = np.full((Ca, La + Lh - 1), poison, np.float32)
+            _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(x), Ca, La, _lib.planar_ptrs(h), Ci, Lh, B, keep, _lib.planar_ptrs(out)))
+            nwk = min(La + Lh - 1, (La // B + -(-Lh // B)) * B)            # what the reference keeps
+            nw = nwk if keep else La + Lh - 1
+            assert not (out == poison).any() and not out[:, nw:].any()
+            ref, _ = oracle.convolve_periodic(x, h, B)
+            for c in range(Ca):
+                assert rel_rms(out[c, :nwk], ref[c, :nwk]) < RMS_TOL
+                if not keep and nw > nwk:                                    # the flushed tail: against float64
+                    hh = (h[0].astype(np.float64) + h[1]) / 2 if (Ci == 2 and Ca == 1) else h[c if Ci == Ca else 0].astype(np.float64)
+                    full = scipy.signal.fftconvolve(x[c].astype(np.float64), hh)
+                    assert np.abs(out[c, nwk:] - full[nwk:]).max() < 1e-5 * max(np.abs(full).max(), 1e-30)
+        lib.irb_release_cached_plans()
+
+
 def test_delta_ir_is_pure_delay():
     x = np.stack([white_noise(11, 8192), white_noise(12, 8192)])
     y = convolvePeriodic(x, delta_ir()[None], 256)
