@@ -1620,22 +1620,30 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     OfflineEngineGuard &g = g_offline;
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
-    {
-        // The IR's upload, partition FFTs and transposes (a chain of ~8 short device operations, ~50 us with their launch gaps) touch
-        // nothing the audio's forward FFTs touch: they run on a stream of their own, beside the first of those, and the engine's
-        // stream waits for them in front of the multiply (tiled_mac's first launch is behind this event wait for every call below).
-        // (No ordering against the reset is needed: it clears the FDL, the IR set-up writes the IR tables; the previous call on this
-        // engine has been waited for before it returned.)
+    // The IR's upload, partition FFTs and transposes (a chain of ~8 short device operations, ~50 us with their launch gaps) touch
+    // nothing the audio's forward FFTs touch: they run on a stream of their own, beside the first of those, and the engine's
+    // stream waits for them in front of the multiply (tiled_mac's first launch is behind this event wait for every call below).
+    // (No ordering against the reset is needed: it clears the FDL, the IR set-up writes the IR tables; the previous call on this
+    // engine has been waited for before it returned.)  The HOST part of it -- the IR's samples copied into pinned staging, 0.1 ms
+    // for a 10-second stereo IR -- is done after the first forward-FFT launch has been issued, so the device is already reading
+    // the audio meanwhile.
+    bool ir_started = false;
+    auto start_ir = [&]() -> int {
+        if (ir_started) return IRB_OK;
+        ir_started = true;
         hipStream_t main_stream = h->stream;
         h->stream = g.s_ir;
-        rc = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
+        int r = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
         hipError_t e = hipSuccess;
-        if (rc == IRB_OK && (e = hipEventRecord(g.ev_ir, g.s_ir)) != hipSuccess) rc = fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
+        if (r == IRB_OK && (e = hipEventRecord(g.ev_ir, g.s_ir)) != hipSuccess) r = fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
         h->stream = main_stream;
-        if (rc != IRB_OK) { (void) hipStreamSynchronize(g.s_ir); return rc; }
-    }
+        if (r != IRB_OK) (void) hipStreamSynchronize(g.s_ir);
+        return r;
+    };
     // every path below calls this in front of its multiply
     auto join_ir = [&]() -> int {
+        int r = start_ir();
+        if (r != IRB_OK) return r;
         hipError_t e = hipStreamWaitEvent(h->stream, g.ev_ir, 0);
         return e == hipSuccess ? IRB_OK : fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
     };
@@ -1678,7 +1686,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
                 rc = tiled_push(h, call, 0, T);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
-                if (rc == IRB_OK) rc = join_ir();
+                if (rc == IRB_OK) rc = join_ir();                            // (the first piece starts the IR's set-up here, behind its forward FFTs)
                 if (rc == IRB_OK) rc = tiled_mac(h, call);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
                 if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
@@ -1718,6 +1726,8 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         ranges.release();                                            // registration refused (read-only mapping, exotic memory): staged copies
     }
 
+    rc = start_ir();                                                 // staged form: the calling thread is about to be busy packing
+    if (rc != IRB_OK) return rc;
     const long stride = (long) h->Tmax * h->B;
     float *const host_in = h->h_io, *const host_out = h->h_io + (size_t) audio_ch * stride;
     float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
