@@ -202,8 +202,9 @@ int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_float
  * dropped tail (only (floor(La/B)+P)*B samples are written, the rest stay 0,
  * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.
  * `out` must not overlap `audio` (the reference returns a new buffer; IRB_ERR_ARG otherwise).  For the duration of the call the
- * audio and result buffers are registered with the HIP runtime and the kernels read / write them in place (no host copy of the
- * signal); where the runtime refuses that, the call goes through pinned staging instead (irb_convolve_last_profile tells).
+ * audio, impulse-response and result buffers are registered with the HIP runtime and the kernels read / write them in place (no
+ * host copy of the signal or of the IR); where the runtime refuses that, the call goes through pinned staging instead
+ * (irb_convolve_last_profile tells).
  * The calling thread's engine (device buffers, pinned staging, streams) is kept for the next call of a similar size;
  * it is freed by irb_release_cached_plans() (irb_deconv.h) or when the thread exits.        */
 int  irb_convolve_periodic(int device,
@@ -229,15 +230,15 @@ int  irb_device_quiet_end(int device);
 typedef struct irb_convolve_profile {
     double total_ms;            /* the whole call                                                           */
     double setup_ms;            /* engine look-up (or creation: engine_created), FDL reset, IR upload + transform enqueued */
-    double register_ms;         /* direct form: hipHostRegister of the caller's audio and result buffers     */
+    double register_ms;         /* direct form: hipHostRegister of the caller's audio, IR and result buffers */
     double pack_ms;             /* staged form, calling thread: caller's audio -> pinned staging             */
     double unpack_ms;           /* staged form, calling thread: pinned staging -> caller's out (its share of the chunks) */
     double unpack_helper_ms;    /* staged form, unpacking thread: the same for the other chunks              */
     double wait_ms;             /* calling thread blocked on the device (direct: the one wait of the call)   */
     double wait_helper_ms;      /* staged form: unpacking thread blocked on output chunks' events            */
     double stall_ms;            /* staged form: calling thread waiting for the unpacking thread at the end   */
-    double fft_in_ms;           /* device: forward FFTs of all blocks (direct: reading the caller's audio over PCIe; staged: also the
-                                   host's packing it waits for, and the multiply)                           */
+    double fft_in_ms;           /* device: the IR's partition FFTs + forward FFTs of all blocks (direct: reading the caller's IR and audio
+                                   over PCIe; staged: also the host's packing it waits for, and the multiply)  */
     double mac_ms;              /* device: the multiply-accumulate (direct form; -1 in the staged form)     */
     double fft_out_ms;          /* device: inverse FFTs + overlap-add of all blocks, written to the caller's buffer / the staging */
     double device_ms;           /* device: first forward-FFT launch -> last inverse-FFT launch done          */

@@ -821,8 +821,6 @@ struct HostRanges {
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
     std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
-    hipStream_t s_ir = nullptr;                        // the IR's upload and transforms run beside the audio's forward FFTs ...
-    hipEvent_t ev_ir = nullptr;                        // ... and join the engine's stream before the multiply
     Unpacker unpacker;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -833,12 +831,10 @@ struct OfflineEngineGuard {
         DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
         (void) hipSetDevice(eng->device);
         (void) irb_sync(eng);
-        if (s_ir) { (void) hipStreamSynchronize(s_ir); (void) hipStreamDestroy(s_ir); s_ir = nullptr; }
         irb_fdl_destroy(eng);
         eng = nullptr;
         for (auto &e : ev) if (e) (void) hipEventDestroy(e);
         ev.clear();
-        if (ev_ir) { (void) hipEventDestroy(ev_ir); ev_ir = nullptr; }
     }
     ~OfflineEngineGuard() { release(); }
 };
@@ -1108,8 +1104,12 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
     }
     const int first_set = instance * h->C;
     if (np > 0) {
-        HIP_TRY(COPY_ASYNC(h, h->d_irtime, stage, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
-        int rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
+        int rc;
+        if (h->host_io && h->d_hir) rc = launch_ir_fft(h, h->d_hir + (stage - h->h_ir), np, nrows, first_set, 0);   // the kernel reads the pinned staging itself: no copy command in front of it
+        else {
+            HIP_TRY(COPY_ASYNC(h, h->d_irtime, stage, sizeof(float) * row * nrows, hipMemcpyHostToDevice, h->stream));
+            rc = launch_ir_fft(h, h->d_irtime, np, nrows, first_set, 0);
+        }
         if (rc != IRB_OK) return rc;
     }
     // the time-tiled kernels walk partitions in groups of kPadP: rows up to the next multiple stay zero
@@ -1130,6 +1130,38 @@ int irb_fdl_set_ir(irb_fdl *h, int instance, const float *const *ir, int ir_chan
     h->ir_used[slot] = true;
     h->ir_slot ^= 1;
     return IRB_OK;
+}
+
+// irb_fdl_set_ir's work for instance 0 of the one-shot function's engine when the caller's impulse response is device-readable
+// (registered for the call): ONE launch transforms it where it lies (k_ir_fft_direct: no pinned staging copy on the host, no copy
+// command, zero rows and stream records written by the same launch) + the tap-contiguous copy for the matrix cores.  d_ir: device
+// pointers of the caller's channels; they must stay valid until the stream has been waited for.
+static int set_ir_direct(irb_fdl *h, const float *const *d_ir, int ir_channels, int len)
+{
+    if (len < 0 || len > h->P * h->B) return fail(IRB_ERR_ARG, "IR length %d exceeds max_ir_len capacity %d", len, h->P * h->B);
+    if (!((ir_channels == 1 || ir_channels == 2) && (h->C == 1 || h->C == 2)))
+        return fail(IRB_ERR_LAYOUT, "Either audio (%d ch) or IR (%d ch) is not mono nor stereo", h->C, ir_channels);
+    const int np = (len + h->B - 1) / h->B;
+    const int nrows = (ir_channels == 2 && h->C == 2) ? 2 : 1;        // fp/convolution.cpp:94-101
+    const int np_pad = std::min((np + kPadP - 1) / kPadP * kPadP, h->Ppad);
+    for (int c = 0; c < h->C; c++) {
+        h->h_set_of_stream[c] = nrows == 2 ? c : 0;                   // fp/convolution.cpp:176-181
+        h->h_np_of_set[c] = np;
+    }
+    update_pairing(h);
+    irb::IrDirectArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.src[0] = d_ir[0]; a.src[1] = ir_channels == 2 ? d_ir[1] : d_ir[0];
+    a.H = h->d_H; a.tw = h->d_tw; a.stream_info = h->d_stream_info;
+    a.ninfo = h->C;
+    for (int c = 0; c < h->C; c++) a.info[c] = make_int2(h->h_set_of_stream[c], h->h_np_of_set[h->h_set_of_stream[c]]);
+    a.average = (ir_channels == 2 && h->C == 1) ? 1 : 0;              // tools::sumToMono, fp/tools.cpp:25-28
+    a.nrows = nrows; a.len = len; a.B = h->B; a.P = h->Ppad; a.first_set = 0; a.np = np; a.np_pad = np_pad;
+    h->n_launches++;
+    const int items = std::max(1, nrows * np_pad);
+    FOR_N(h->N, irb::k_ir_fft_direct<NN><<<dim3((items + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a));
+    HIP_TRY(hipGetLastError());
+    return launch_ht(h, 0, nrows, np);
 }
 
 int irb_fdl_set_ir_partition(irb_fdl *h, int instance, int partition, const float *samples)
@@ -1612,41 +1644,26 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         hipError_t e = hipSuccess;
         g_offline.ev.assign((size_t) 4 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
         for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_offline.s_ir, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_offline.ev_ir, hipEventDisableTiming);
         if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
     OfflineEngineGuard &g = g_offline;
     int rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return rc;
-    // The IR's upload, partition FFTs and transposes (a chain of ~8 short device operations, ~50 us with their launch gaps) touch
-    // nothing the audio's forward FFTs touch: they run on a stream of their own, beside the first of those, and the engine's
-    // stream waits for them in front of the multiply (tiled_mac's first launch is behind this event wait for every call below).
-    // (No ordering against the reset is needed: it clears the FDL, the IR set-up writes the IR tables; the previous call on this
-    // engine has been waited for before it returned.)  The HOST part of it -- the IR's samples copied into pinned staging, 0.1 ms
-    // for a 10-second stereo IR -- is done after the first forward-FFT launch has been issued, so the device is already reading
-    // the audio meanwhile.
+    // The IR's set-up (partition FFTs straight out of the pinned staging, zero rows, the tap-contiguous copy for the matrix cores, the
+    // stream records: four short device operations, ~20 us) goes on the engine's own stream BEHIND the first forward-FFT launch:
+    // the device does not overlap the two anyway (rocprofv3 timeline, profiles/r04_oneshot_timeline.txt: on a second stream the
+    // set-up's kernels started when the forward FFTs' workgroups retired, and the join in front of the multiply cost another
+    // ~20 us of idle device), and the HOST part -- the IR's samples copied into pinned staging, 0.1 ms for a 10-second stereo IR --
+    // now happens while the device already pulls the audio over PCIe.
     bool ir_started = false;
     auto start_ir = [&]() -> int {
         if (ir_started) return IRB_OK;
         ir_started = true;
-        hipStream_t main_stream = h->stream;
-        h->stream = g.s_ir;
-        int r = irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
-        hipError_t e = hipSuccess;
-        if (r == IRB_OK && (e = hipEventRecord(g.ev_ir, g.s_ir)) != hipSuccess) r = fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
-        h->stream = main_stream;
-        if (r != IRB_OK) (void) hipStreamSynchronize(g.s_ir);
-        return r;
+        return irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
     };
     // every path below calls this in front of its multiply
-    auto join_ir = [&]() -> int {
-        int r = start_ir();
-        if (r != IRB_OK) return r;
-        hipError_t e = hipStreamWaitEvent(h->stream, g.ev_ir, 0);
-        return e == hipSuccess ? IRB_OK : fail(IRB_ERR_HIP, "IR stream: %s", hipGetErrorString(e));
-    };
+    auto join_ir = [&]() -> int { return start_ir(); };
     // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves (both registered for the
     // call): no host copy at all, one launch per phase.  Taken unless registration is refused (then the staged pipeline below runs).
     bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
@@ -1658,13 +1675,28 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         DeviceQuiet quiet(device);
         HostRanges ranges;
         float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
+        const float *d_irp[2] = {nullptr, nullptr};
+        // the impulse response too, when the runtime accepts its pages (a read-only mapping is refused: the staged set-up serves then)
+        bool ir_direct = env_int("IRB_OFFLINE_IR_DIRECT", 1) != 0 && Lh_eff > 0;
         ranges.add(audio, audio_ch, (size_t) La);
         ranges.add(out, audio_ch, (size_t) Lout);
+        if (ir_direct) ranges.add(ir, ir_ch, (size_t) Lh_eff);
         bool ok = ranges.commit();
+        if (!ok && ir_direct) {
+            ranges.release();
+            ir_direct = false;
+            ranges.add(audio, audio_ch, (size_t) La);
+            ranges.add(out, audio_ch, (size_t) Lout);
+            ok = ranges.commit();
+        }
         for (int c = 0; c < audio_ch && ok; c++) {
             d_audio[c] = ranges.dev(audio[c]);
             d_res[c] = ranges.dev(out[c]);
             ok = d_audio[c] && d_res[c];
+        }
+        for (int c = 0; c < ir_ch && ok && ir_direct; c++) {
+            d_irp[c] = ranges.dev(ir[c]);
+            if (!d_irp[c]) ir_direct = false;
         }
         const long in_stride = audio_ch == 2 && ok ? (long) (d_audio[1] - d_audio[0]) : 0, out_stride = audio_ch == 2 && ok ? (long) (d_res[1] - d_res[0]) : 0;
         if (ok) {
@@ -1673,6 +1705,14 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             const bool device_times = g_offline_profile_events;
             float dev_ms[4] = {0, 0, 0, 0};
             int pieces = 0, mac_launches = 1;
+            if (ir_direct) {
+                // the IR transformed where it lies, in FRONT of the forward FFTs: both pull their samples over PCIe, so one after the other
+                // costs the link's time once, and nothing of the IR's set-up is left between the forward FFTs and the multiply
+                // (rocprofv3 timelines in profiles/NOTES.md: behind them it was 27 us of device time + two gaps)
+                if (device_times) (void) hipEventRecord(g.ev[0], h->stream);   // (the profile counts it with the forward FFTs: "in")
+                rc = set_ir_direct(h, d_irp, ir_ch, Lh_eff);
+                ir_started = true;
+            }
             for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
                 const int T = (int) std::min<long>(Tneed, steps - p0);
                 irb::StepArgs a = step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride);
@@ -1683,7 +1723,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 rc = tiled_begin(h, a, T, &call);
                 if (rc != IRB_OK) break;
                 mac_launches = call.mfma ? call.plan.n : 1;
-                if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
+                if (device_times && !(ir_direct && pieces == 0)) (void) hipEventRecord(g.ev[0], h->stream);
                 rc = tiled_push(h, call, 0, T);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
                 if (rc == IRB_OK) rc = join_ir();                            // (the first piece starts the IR's set-up here, behind its forward FFTs)

@@ -1393,6 +1393,63 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft(const float *
     wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_ir_fft_direct: the same transform straight out of the CALLER's impulse response (registered host memory or device memory),
+// for the one-shot function: no staging copy on the host, no copy command, and what irb_fdl_set_ir does around its k_ir_fft
+// in separate device operations folded in -- the zero rows up to the tile period (rows np .. np_pad), the stream records.
+// Row r of the spectra = source r, or (average = 1) (src[0] + src[1]) / 2 sample by sample, the host's order of operations
+// (tools::sumToMono, fp/tools.cpp:25-28); samples at and beyond `len` read as zeros (fp/convolution.cpp:106-118).
+// one wave per row of H: grid = ceil(nrows * np_pad / NF).
+// ---------------------------------------------------------------------------------------------
+struct IrDirectArgs {
+    const float *src[2];
+    float2 *H;                   // [set][P][M]
+    const float2 *tw;
+    int2 *stream_info;           // records [0, ninfo) are written by the launch (nullptr: none)
+    int2 info[2];
+    int ninfo, average, nrows, len, B, P, first_set, np, np_pad;
+};
+
+template <int N>
+__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft_direct(IrDirectArgs a)
+{
+    constexpr int M = N / 2, NF = FftGeom<N>::NF;
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[NF][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (blockIdx.x == 0 && threadIdx.x < a.ninfo && a.stream_info) a.stream_info[threadIdx.x] = a.info[threadIdx.x];
+    const int item = blockIdx.x * NF + wave;
+    const bool live = item < a.nrows * a.np_pad;
+    const int k = live ? item % a.np_pad : 0, r = live ? item / a.np_pad : 0;
+    float2 *dst = a.H + ((size_t) (a.first_set + r) * a.P + k) * M;
+    if (live && k >= a.np) {                           // a zero row behind the IR's partitions (wave-uniform)
+        for (int b = lane; b < M; b += kWave) dst[b] = make_float2(0.f, 0.f);
+    }
+    const bool fft = live && k < a.np;
+    TwiddleStage<N, kWave * NF> tws;
+    tws.load(a.tw);
+    if (fft) {
+        float *zf = reinterpret_cast<float *>(l_buf[wave]);
+        const float *s0 = a.src[a.average ? 0 : r], *s1 = a.src[1];
+        const long base = (long) k * a.B;
+        for (int n = lane; n < N; n += kWave) {
+            const long idx = base + n;
+            float v = 0.0f;
+            if (n < a.B && idx < a.len) {
+                v = s0[idx];
+                if (a.average) { v += s1[idx]; v /= 2.0f; }
+            }
+            zf[n] = v;
+        }
+        wave_sync();
+    }
+    tws.store(l_tw);
+    __syncthreads();
+    if (!fft) return;
+    wave_fft<M, false>(l_buf[wave], l_tw, lane);
+    wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
+}
+
 }  // namespace irb
 
 #include "fdl_tiled_pk.hpp"

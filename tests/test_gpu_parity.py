@@ -218,6 +218,52 @@ def test_convolve_periodic_writes_every_sample_of_the_result(monkeypatch, direct
         lib.irb_release_cached_plans()
 
 
+def test_convolve_periodic_reads_the_impulse_response_where_it_lies(tmp_path, monkeypatch):
+    """The direct form transforms the caller's impulse response in place (k_ir_fft_direct: no staging copy): all four channel layouts
+    incl. the stereo IR averaged for mono audio (tools::sumToMono, fp/tools.cpp:25-28), ragged IR lengths, an IR in the SAME
+    allocation as the audio (one registration) -- each against the oracle and bit-identical to the staged IR set-up
+    (IRB_OFFLINE_IR_DIRECT=0).  An IR in a read-only file mapping is refused by the runtime's registration: the call then
+    falls back (audio still direct) and gives the same samples."""
+    import ctypes
+    lib = _lib.lib()
+    B = 128
+    prof = _lib.ConvolveProfile()
+    for Ca, Ci, La, Lh in ((1, 1, 40000, 3001), (2, 2, 33000, 128 * 7), (2, 1, 12345, 999), (1, 2, 20000, 5000)):
+        x = np.stack([white_noise(8300 + c, La) for c in range(Ca)])
+        h = np.stack([decaying_ir(8310 + c, Lh) for c in range(Ci)])
+        ref, _ = oracle.convolve_periodic(x, h, B)
+        outs = []
+        for direct in ("1", "0"):
+            monkeypatch.setenv("IRB_OFFLINE_IR_DIRECT", direct)
+            outs.append(convolvePeriodic(x, h, B))
+        monkeypatch.delenv("IRB_OFFLINE_IR_DIRECT")
+        assert np.array_equal(outs[0], outs[1])
+        for c in range(Ca):
+            assert rel_rms(outs[0][c], ref[c]) < RMS_TOL
+    # audio and IR in one allocation
+    La, Lh = 30000, 2000
+    big = np.zeros((1, La + Lh + 13), np.float32)
+    big[0, 5:5 + La] = white_noise(8350, La)
+    big[0, 5 + La + 3:5 + La + 3 + Lh] = decaying_ir(8351, Lh)
+    xa, ha = big[:, 5:5 + La], big[:, 5 + La + 3:5 + La + 3 + Lh]
+    out = np.empty((1, La + Lh - 1), np.float32)
+    fpp = lambda arrs: (_lib.fp * len(arrs))(*[a.ctypes.data_as(_lib.fp) for a in arrs])
+    _lib.check(lib.irb_convolve_periodic(0, fpp([xa[0]]), 1, La, fpp([ha[0]]), 1, Lh, B, 1, fpp([out[0]])))
+    ref, _ = oracle.convolve_periodic(np.ascontiguousarray(xa), np.ascontiguousarray(ha), B)
+    assert rel_rms(out[0], ref[0]) < RMS_TOL
+    # an IR the process may only read
+    path = tmp_path / "ir.f32"
+    decaying_ir(8360, 4096).tofile(path)
+    hm = np.memmap(path, dtype=np.float32, mode="r")
+    x = white_noise(8361, 50000)[None]
+    y = np.empty((1, 50000 + 4096 - 1), np.float32)
+    _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(x), 1, 50000, fpp([hm]), 1, 4096, B, 1, _lib.planar_ptrs(y)))
+    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
+    ref, _ = oracle.convolve_periodic(x, np.array(hm)[None], B)
+    assert rel_rms(y[0], ref[0]) < RMS_TOL
+    lib.irb_release_cached_plans()
+
+
 def test_delta_ir_is_pure_delay():
     x = np.stack([white_noise(11, 8192), white_noise(12, 8192)])
     y = convolvePeriodic(x, delta_ir()[None], 256)
