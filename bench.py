@@ -306,8 +306,9 @@ def one_shot(dev, np, decaying_ir, white_noise, Ca, Ci, Bk, Lh, La, note, reps=2
            "pcie_bytes": 4 * (Ca * La + Ca * (La + Lh - 1) + Ci * Lh), "pcie_GBps_both_ways": round(4 * (Ca * La + Ca * (La + Lh - 1)) / ms / 1e6, 2),
            "breakdown_ms": med,
            "breakdown_note": "irb_convolve_last_profile, medians over 7 further calls with device events on (those calls wait once more per piece, so "
-                             "their total_ms runs a few us above wall_ms_c_abi).  direct=1: the kernels read the caller's audio and write the caller's "
-                             "result buffer themselves (both registered for the call; no host copy): fft_in_ms / fft_out_ms are PCIe-bound, mac_ms is "
+                             "their total_ms runs a few us above wall_ms_c_abi).  direct=1: the kernels read the caller's audio and impulse response and write the "
+                             "caller's result buffer themselves (registered for the call; no host copy): fft_in_ms (the IR's partition FFTs + the forward "
+                             "FFTs) and fft_out_ms are PCIe-bound, mac_ms is "
                              "the multiply over ALL blocks of the signal in mac_launches launches (chunks = pieces = multiplies, blocks_per_chunk = "
                              "blocks per multiply)",
            "note": note + "; pageable numpy buffers, wall clock, engine cached from the first call"}
