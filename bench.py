@@ -261,9 +261,60 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
     res["configs[2]_one_shot"] = one_shot(dev, np, decaying_ir, white_noise, 2, 2, 128, 480000, 1920000,
                                           "configs[2] (stereo, B=128, 10 s IR, 40 s of audio: 18750 block steps = two multiplies, the FDL carried "
                                           "between them) through the drop-in function", reps=7)
+    res["configs[1]_nonperiodic_one_shot"] = nonperiodic_one_shot(dev, np, decaying_ir, white_noise)
     res["rt_processBlock"] = rt_process_block(dev, np)
     res.update(config5(dev, np))
     return res
+
+
+def nonperiodic_one_shot(dev, np, decaying_ir, white_noise, La=960000, Lh=96000, reps=15):
+    """fp::convolution::convolveNonPeriodic (fp/convolution.cpp:246-347; SURVEY 8 f-4) on configs[1]'s signal: ONE FFT of
+    N = 2^21 >= La + Lh - 1 per signal, bin-wise product, inverse -- irb_convolve_nonperiodic from pageable host buffers, wall clock."""
+    from irbaboon_amd import _lib, convolveNonPeriodic
+    from irbaboon_amd._lib import planar_ptrs
+    x, h = white_noise(4200, La)[None], decaying_ir(4201, Lh)[None]
+    lib = _lib.lib()
+    convolveNonPeriodic(x, h, device=dev)                             # builds the calling thread's plan
+    ta, tb = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        convolveNonPeriodic(x, h, device=dev)
+        ta.append(time.perf_counter() - t0)
+    out = np.zeros((1, La + Lh - 1), np.float32)
+    xp, hp, op = planar_ptrs(x), planar_ptrs(h), planar_ptrs(out)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rc = lib.irb_convolve_nonperiodic(dev, xp, 1, La, hp, 1, Lh, op)
+        tb.append(time.perf_counter() - t0)
+        if rc != 0:
+            raise SystemExit("irb_convolve_nonperiodic failed: " + lib.irb_last_error().decode())
+    ms = float(np.median(tb)) * 1e3
+    n = 1
+    while n < La + Lh - 1:
+        n *= 2
+    ent = {"wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(min(tb) * 1e3, 4),
+           "fft_len": n, "samples": La, "Msamples_per_s": round(La / ms / 1e3, 1), "calls_timed": reps,
+           "pcie_GBps_both_ways": round(4 * (La + Lh + La + Lh - 1) / ms / 1e6, 2),
+           "note": "irb_convolve_nonperiodic, mono, 20 s of audio through a 2 s IR as one 2^21-point transform per signal; pageable numpy buffers, "
+                   "wall clock, plan cached from the first call; parity: tests/test_gpu_cfg5.py and the goldens"}
+    lib.irb_release_cached_plans()
+    return ent
+
+
+def cpu_nonperiodic(np, ent, La=960000, Lh=96000, reps=3):
+    """cpu_baseline leg: the oracle's convolveNonPeriodic for the same call (one core)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from irbaboon_amd.synth import decaying_ir, white_noise
+    oracle.use_native()
+    x, h = white_noise(4200, La)[None], decaying_ir(4201, Lh)[None]
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.convolve_nonperiodic(x, h)
+        ts.append(time.perf_counter() - t0)
+    ent["cpu_oracle_ms_1_core"] = round(float(np.median(ts)) * 1e3, 2)
+    ent["speedup_vs_cpu_oracle"] = round(ent["cpu_oracle_ms_1_core"] / ent["wall_ms_c_abi"], 1)
 
 
 def one_shot(dev, np, decaying_ir, white_noise, Ca, Ci, Bk, Lh, La, note, reps=21):
@@ -668,6 +719,7 @@ def main():
         if "other_configs" in out:                    # the oracle's time for the two one-shot calls, beside the GPU's (same leg: the oracle is the CPU baseline)
             cpu_one_shot(np, out["other_configs"]["configs[0]_one_shot"], 1, 1, 256, 4096, 480000, 5)
             cpu_one_shot(np, out["other_configs"]["configs[1]_one_shot"], 1, 1, 256, 96000, 960000, 3)
+            cpu_nonperiodic(np, out["other_configs"]["configs[1]_nonperiodic_one_shot"])
     for eng, _ in engines:
         eng.close()
     if ranks:

@@ -54,7 +54,10 @@ int  irb_invert_filter(int device, const float *ir, int len, int sample_rate, fl
 /* Replaces: AudioBuffer<float> convolution::convolveNonPeriodic(audio, ir) (fp/convolution.cpp:246-347): one
  * FFT of length N = smallest power of two >= La+Lh-1 per signal, bin-wise product over bins 0..N/2
  * (tools::complexMul), inverse, first La+Lh-1 samples.  Same channel-layout rules and error behaviour as
- * irb_convolve_periodic (unknown layout: cleared output + IRB_ERR_LAYOUT).  out: [audio_ch][La+Lh-1]. */
+ * irb_convolve_periodic (unknown layout: cleared output + IRB_ERR_LAYOUT).  out: [audio_ch][La+Lh-1]; every sample of it is
+ * written (computed, or cleared on an error / empty input).  For the duration of the call the audio, IR and result buffers are
+ * registered with the HIP runtime and the copy engine moves the samples straight between them and the device; the stereo-IR-to-
+ * mono-audio layout and buffers the runtime refuses to register go through host staging instead. */
 int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch, int La,
                               const float *const *ir, int ir_ch, int Lh, float *const *out);
 

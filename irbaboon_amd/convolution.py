@@ -55,7 +55,8 @@ def convolveNonPeriodic(buffer1, buffer2, device=0):
     one large FFT per signal on the GPU.  Unknown layout: cleared buffer + debug line (:271-275)."""
     a = np.ascontiguousarray(np.atleast_2d(buffer1), np.float32)
     h = np.ascontiguousarray(np.atleast_2d(buffer2), np.float32)
-    out = np.zeros((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
+    # (every sample of `out` is written by the call -- computed, or cleared: the layout error, empty inputs)
+    out = np.empty((a.shape[0], max(a.shape[1] + h.shape[1] - 1, 0)), np.float32)
     rc = _lib.lib().irb_convolve_nonperiodic(device, planar_ptrs(a), a.shape[0], a.shape[1],
                                              planar_ptrs(h), h.shape[0], h.shape[1], planar_ptrs(out))
     if rc == _lib.IRB_ERR_LAYOUT:

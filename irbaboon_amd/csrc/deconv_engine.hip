@@ -6,6 +6,8 @@
 // for them.
 #include "../../include/irb_deconv.h"
 #include "lfft_kernels.hpp"
+#include "host_ranges.hpp"
+#include "../../include/irb_fdl.h"
 
 #include <algorithm>
 #include <cmath>
@@ -784,14 +786,14 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
 {
     if (!audio || !ir || !out || La < 0 || Lh < 0 || audio_ch < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
     const long Lout = (long) La + Lh - 1;                             // :251
-    for (int c = 0; c < audio_ch; c++) {
-        if (!out[c]) return irb_set_error_(IRB_ERR_ARG, "null output channel");
-        if (Lout > 0) std::memset(out[c], 0, sizeof(float) * (size_t) Lout);
-    }
-    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2)))   // :262-275
+    for (int c = 0; c < audio_ch; c++) if (!out[c]) return irb_set_error_(IRB_ERR_ARG, "null output channel");
+    auto clear_out = [&]() { for (int c = 0; c < audio_ch; c++) if (Lout > 0) std::memset(out[c], 0, sizeof(float) * (size_t) Lout); };
+    if (!((ir_ch == 1 || ir_ch == 2) && (audio_ch == 1 || audio_ch == 2))) {   // :262-275: a cleared buffer + the debug line
+        clear_out();
         return irb_set_error_(IRB_ERR_LAYOUT, "Either buffer1 or buffer2 is not mono nor stereo. Abort abort");
-    if (Lout <= 0 || La == 0 || Lh == 0) return IRB_OK;
-    if (Lout > (1 << 23)) return irb_set_error_(IRB_ERR_ARG, "result longer than 2^23 samples");
+    }
+    if (Lout <= 0 || La == 0 || Lh == 0) { clear_out(); return IRB_OK; }
+    if (Lout > (1 << 23)) { clear_out(); return irb_set_error_(IRB_ERR_ARG, "result longer than 2^23 samples"); }
     int N = 1;
     while (N < Lout) N *= 2;                                          // :278-281
     N = std::max(N, 32);                                              // longer zero padding: same linear convolution
@@ -799,7 +801,49 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
     const int batch = audio_ch + ir_rows;
     irb_lfft *p = nullptr;
     int rc = cached_plan(device, N, batch, &p);
-    if (rc != IRB_OK) return rc;
+    if (rc != IRB_OK) { clear_out(); return rc; }
+    // ---- direct form (like irb_convolve_periodic's): the caller's audio, IR and result buffers are registered with the runtime for the
+    // call, the copy engine moves the samples straight between them and the device (zero padding = one device memset), no host
+    // copy at all.  Not for the stereo-IR-to-mono-audio layout (its average is taken on the host below) and not when the runtime
+    // refuses a registration: the staged form below serves then.
+    const char *env_direct = std::getenv("IRB_NONPERIODIC_DIRECT");   // (0: the staged form, for A/B and tests)
+    const bool want_direct = !(env_direct && env_direct[0] == '0');
+    if (want_direct && !(ir_ch == 2 && audio_ch == 1)) {
+        (void) irb_device_quiet_begin(device);                        // registration is a device-wide operation for the runtime (irb_fdl.h)
+        struct Quiet { int d; ~Quiet() { (void) irb_device_quiet_end(d); } } quiet{device};
+        HostRanges ranges;
+        ranges.add(audio, audio_ch, (size_t) La);
+        ranges.add(ir, ir_rows, (size_t) Lh);
+        ranges.add(out, audio_ch, (size_t) Lout);
+        if (ranges.commit()) {
+            hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * (size_t) batch * N, p->stream);
+            for (int c = 0; c < audio_ch && e == hipSuccess; c++)
+                e = hipMemcpyAsync(p->d_time + (size_t) c * N, audio[c], sizeof(float) * (size_t) La, hipMemcpyHostToDevice, p->stream);
+            for (int r = 0; r < ir_rows && e == hipSuccess; r++)
+                e = hipMemcpyAsync(p->d_time + (size_t) (audio_ch + r) * N, ir[r], sizeof(float) * (size_t) Lh, hipMemcpyHostToDevice, p->stream);
+            if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "upload", hipGetErrorString(e));
+            if (rc == IRB_OK) rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, batch);
+            const int nbins = N / 2 + 1;
+            for (int c = 0; c < audio_ch && rc == IRB_OK; c++) {
+                const int irc = (ir_rows == 2) ? c : 0;               // :318-323
+                irb::k_cmul<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
+                    reinterpret_cast<float2 *>(p->d_spec + (size_t) c * 2 * N),
+                    reinterpret_cast<const float2 *>(p->d_spec + (size_t) (audio_ch + irc) * 2 * N), nbins);
+            }
+            if (rc == IRB_OK && (e = hipGetLastError()) != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "k_cmul", hipGetErrorString(e));
+            if (rc == IRB_OK) rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, audio_ch);
+            for (int c = 0; c < audio_ch && rc == IRB_OK; c++)        // :340-344: the first La + Lh - 1 samples
+                if ((e = hipMemcpyAsync(out[c], p->d_time + (size_t) c * N, sizeof(float) * (size_t) Lout, hipMemcpyDeviceToHost, p->stream)) != hipSuccess)
+                    rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e));
+            e = hipStreamSynchronize(p->stream);                      // also on failure: nothing may still touch the caller's memory
+            ranges.release();
+            if (rc == IRB_OK && e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "convolveNonPeriodic", hipGetErrorString(e));
+            if (rc != IRB_OK) clear_out();
+            return rc;
+        }
+        ranges.release();
+    }
+    clear_out();
     do {
         std::vector<float> host((size_t) batch * N, 0.0f);
         for (int c = 0; c < audio_ch; c++) std::memcpy(&host[(size_t) c * N], audio[c], sizeof(float) * (size_t) La);

@@ -236,6 +236,36 @@ def test_convolve_nonperiodic_long():
     assert rel_rms(y[0], scipy.signal.fftconvolve(x[0].astype(np.float64), h[0].astype(np.float64))) < 1e-5
 
 
+def test_convolve_nonperiodic_direct_and_staged_forms_agree(monkeypatch):
+    """irb_convolve_nonperiodic moves the samples straight between the caller's (registered) buffers and the device; the staged form
+    (IRB_NONPERIODIC_DIRECT=0: host vectors, pageable copies) is what serves the stereo-IR-to-mono layout and refused registrations.
+    Same kernels either way: identical bits, a poisoned result buffer fully overwritten, for the layouts the direct form takes,
+    ragged lengths, audio and IR in one allocation."""
+    from irbaboon_amd import _lib
+    lib = _lib.lib()
+    fpp = lambda arrs: (_lib.fp * len(arrs))(*[a.ctypes.data_as(_lib.fp) for a in arrs])
+    for k, (Ca, Ci, La, Lh) in enumerate([(1, 1, 50000, 3001), (2, 2, 33001, 777), (2, 1, 12345, 999), (1, 2, 2000, 300), (1, 1, 5, 3)]):
+        big = np.zeros(Ca * La + Ci * Lh + 64, np.float32)           # everything in one allocation, odd offsets
+        xs = [big[3 + c * (La + 1):3 + c * (La + 1) + La] for c in range(Ca)]
+        off = 3 + Ca * (La + 1) + 5
+        hs = [big[off + c * (Lh + 1):off + c * (Lh + 1) + Lh] for c in range(Ci)]
+        for c in range(Ca):
+            xs[c][:] = white_noise(8600 + 10 * k + c, La)
+        for c in range(Ci):
+            hs[c][:] = decaying_ir(8650 + 10 * k + c, Lh)
+        outs = []
+        for direct in ("1", "0"):
+            monkeypatch.setenv("IRB_NONPERIODIC_DIRECT", direct)
+            out = [np.full(La + Lh - 1, 1e30, np.float32) for _ in range(Ca)]
+            _lib.check(lib.irb_convolve_nonperiodic(0, fpp(xs), Ca, La, fpp(hs), Ci, Lh, fpp(out)))
+            outs.append(np.stack(out))
+        assert np.array_equal(outs[0], outs[1]) and not (outs[0] == np.float32(1e30)).any()
+        ref, _ = oracle.convolve_nonperiodic(np.stack(xs), np.stack(hs))
+        for c in range(Ca):
+            assert rel_rms(outs[0][c], ref[c]) < 1e-5
+    lib.irb_release_cached_plans()
+
+
 @pytest.mark.parametrize("n,ps", [(2048, 256), (2000, 256), (700, 64), (96000, 512)])
 def test_ir_to_real_fft_raw_layout(n, ps):
     """ir::IRtoRealFFTRaw (fp/ir.cpp:106-147): len/ps + 1 rows of 2*ps floats, each the partition's FFT with
