@@ -64,7 +64,9 @@ int  irb_convolve_nonperiodic(int device, const float *const *audio, int audio_c
 /* Replaces: ir::IRtoRealFFTRaw(buffer, irPartSize) (fp/ir.cpp:106-147) without its hard-coded text dump:
  * the mono IR cut into len/irPartSize + 1 partitions, each transformed with N = 2*irPartSize and packed
  * (im(0) := re(N/2)), consolidated as rows of N floats.  irPartSize must be a power of two >= 16.
- * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows. */
+ * out_len >= (len/irPartSize + 1) * 2*irPartSize.  Returns the number of rows through *n_rows.  The IR and result buffers are
+ * registered with the HIP runtime for the call (one launch transforms the IR where it lies, one copy brings the rows back; a small
+ * device buffer is kept per calling thread and freed by irb_release_cached_plans()). */
 int  irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);
 
 /* ---- fp::ExpSineSweep, HOST code (the sweep generator stays on the host: one-off O(N) work) --------------

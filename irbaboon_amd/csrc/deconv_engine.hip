@@ -875,7 +875,8 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
 }
 
 // ---- ir::IRtoRealFFTRaw (fp/ir.cpp:106-147) ------------------------------------------------------------
-int irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows)
+// the fallback of irb_ir_to_real_fft_raw (fdl_engine.hip) when the caller's buffers cannot be registered: through a short-lived engine
+int irb_ir_to_real_fft_raw_engine_(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows)
 {
     if (!ir || !out || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
     if (!is_pow2(ir_part_size) || ir_part_size < 16 || ir_part_size > 2048)

@@ -266,6 +266,21 @@ def test_convolve_nonperiodic_direct_and_staged_forms_agree(monkeypatch):
     lib.irb_release_cached_plans()
 
 
+def test_ir_to_real_fft_raw_light_path_equals_the_engine_path(monkeypatch):
+    """irb_ir_to_real_fft_raw transforms the caller's IR where it lies (registered for the call, one launch, one copy back, a small
+    per-thread device buffer) instead of building an engine per call; IRB_RAW_DIRECT=0 is the old path, kept for buffers the runtime
+    refuses to register.  Identical bits, for partition sizes 16 ... 2048, ragged and exact lengths, growing and shrinking IRs."""
+    for n, ps in [(700, 64), (96000, 256), (5, 16), (2048 * 3, 2048), (1000, 512), (96000, 512), (300, 256)]:
+        h = decaying_ir(9000 + n, n)
+        outs = []
+        for direct in ("1", "0"):
+            monkeypatch.setenv("IRB_RAW_DIRECT", direct)
+            outs.append(ib.IRtoRealFFTRaw(h, ps))
+        assert outs[0].shape == (n // ps + 1, 2 * ps) and np.array_equal(outs[0], outs[1])
+    from irbaboon_amd import _lib
+    _lib.lib().irb_release_cached_plans()
+
+
 @pytest.mark.parametrize("n,ps", [(2048, 256), (2000, 256), (700, 64), (96000, 512)])
 def test_ir_to_real_fft_raw_layout(n, ps):
     """ir::IRtoRealFFTRaw (fp/ir.cpp:106-147): len/ps + 1 rows of 2*ps floats, each the partition's FFT with
