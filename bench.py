@@ -262,6 +262,7 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
                                           "configs[2] (stereo, B=128, 10 s IR, 40 s of audio: 18750 block steps = two multiplies, the FDL carried "
                                           "between them) through the drop-in function", reps=7)
     res["configs[1]_nonperiodic_one_shot"] = nonperiodic_one_shot(dev, np, decaying_ir, white_noise)
+    res["configs[1]_ir_spectra_raw"] = ir_spectra_raw(dev, np, decaying_ir)
     res["rt_processBlock"] = rt_process_block(dev, np)
     res.update(config5(dev, np))
     return res
@@ -299,6 +300,21 @@ def nonperiodic_one_shot(dev, np, decaying_ir, white_noise, La=960000, Lh=96000,
                    "wall clock, plan cached from the first call; parity: tests/test_gpu_cfg5.py and the goldens"}
     lib.irb_release_cached_plans()
     return ent
+
+
+def ir_spectra_raw(dev, np, decaying_ir, Lh=96000, ps=256, reps=25):
+    """fp::ir::IRtoRealFFTRaw (fp/ir.cpp:106-147; SURVEY 8 f-3): configs[1]'s 2-second IR as 376 rows of packed partition spectra,
+    irb_ir_to_real_fft_raw from a pageable buffer, wall clock (round 3 built and destroyed an engine per call: 4.9 ms)."""
+    from irbaboon_amd import IRtoRealFFTRaw
+    h = decaying_ir(4300, Lh)
+    raw = IRtoRealFFTRaw(h, ps, device=dev)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        IRtoRealFFTRaw(h, ps, device=dev)
+        ts.append(time.perf_counter() - t0)
+    return {"wall_ms_python_mirror": round(float(np.median(ts)) * 1e3, 4), "rows": int(raw.shape[0]), "floats_per_row": int(raw.shape[1]),
+            "note": "irb_ir_to_real_fft_raw: the IR transformed where it lies (registered for the call), one launch + one copy back; parity: tests/test_gpu_cfg5.py"}
 
 
 def cpu_nonperiodic(np, ent, La=960000, Lh=96000, reps=3):
