@@ -51,6 +51,8 @@ def test_committed_bench_line_follows_contract():
     assert e2["breakdown_ms"]["direct"] == 1 and e2["breakdown_ms"]["pieces"] == 2 and 0 < e2["wall_ms_c_abi"] < 6.0
     enp = d["other_configs"]["configs[1]_nonperiodic_one_shot"]             # convolveNonPeriodic, one 2^21-point transform per signal
     assert enp["fft_len"] == 1 << 21 and 0 < enp["wall_ms_c_abi_min"] <= enp["wall_ms_c_abi"] < 0.6 and enp["cpu_oracle_ms_1_core"] > 100 * enp["wall_ms_c_abi"]
+    raw = d["other_configs"]["configs[1]_ir_spectra_raw"]                    # IRtoRealFFTRaw without an engine per call
+    assert raw["rows"] == 376 and raw["floats_per_row"] == 512 and 0 < raw["wall_ms_python_mirror"] < 1.0
     assert d["other_configs"]["configs[1]_offline_one_stream"]["mac_kernel"] == "k_cmac_mfma"
     assert d["other_configs"]["configs[1]_x2048_8_blocks_per_call"]["mac_kernel"] == "k_tile8_fused"
     # the two paths that had no number in the line
