@@ -201,10 +201,16 @@ int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_float
  * [audio_ch][La+Lh-1].  keep_reference_tail != 0 reproduces the reference's
  * dropped tail (only (floor(La/B)+P)*B samples are written, the rest stay 0,
  * fp/convolution.cpp:233-238); 0 writes the complete linear convolution.
- * `out` must not overlap `audio` (the reference returns a new buffer; IRB_ERR_ARG otherwise).  For the duration of the call the
- * audio, impulse-response and result buffers are registered with the HIP runtime and the kernels read / write them in place (no
- * host copy of the signal or of the IR); where the runtime refuses that, the call goes through pinned staging instead
- * (irb_convolve_last_profile tells).
+ * `out` must not overlap `audio` (the reference returns a new buffer; IRB_ERR_ARG otherwise).
+ * How the samples reach the device.  Buffers in ordinary (pageable) memory -- a juce::AudioBuffer, a std::vector, a numpy array
+ * -- are NEVER made device-visible: their samples pass through the library's own pinned staging ("staged form": chunks packed by
+ * up to IRB_OFFLINE_THREADS host threads, default 3 with the caller, while the device already transforms the chunks before).
+ * When audio AND out are HIP host memory already (irb_host_alloc, hipHostMalloc, or registered by the caller itself) the kernels
+ * read and write them in place ("direct form", no host copy); the same for the impulse response on its own.
+ * IRB_OFFLINE_DIRECT=1 opts in to registering pageable buffers with the runtime for the duration of the call (the round-4
+ * default; faster by ~0.1 ms per call, but two calls in ~400 000 read a few stale pages of a registered pageable input --
+ * INTEGRATION.md section 1); IRB_OFFLINE_DIRECT=0 forbids the direct form altogether.  irb_convolve_last_profile tells which
+ * form a call took.  On any error the result buffer is cleared (the reference's give-up value, fp/convolution.cpp:39-42).
  * The calling thread's engine (device buffers, pinned staging, streams) is kept for the next call of a similar size;
  * it is freed by irb_release_cached_plans() (irb_deconv.h) or when the thread exits.        */
 int  irb_convolve_periodic(int device,
@@ -230,7 +236,7 @@ int  irb_device_quiet_end(int device);
 typedef struct irb_convolve_profile {
     double total_ms;            /* the whole call                                                           */
     double setup_ms;            /* engine look-up (or creation: engine_created), FDL reset, IR upload + transform enqueued */
-    double register_ms;         /* direct form: hipHostRegister of the caller's audio, IR and result buffers */
+    double register_ms;         /* direct form: resolving (opt-in: hipHostRegister-ing) the caller's audio, IR and result buffers */
     double pack_ms;             /* staged form, calling thread: caller's audio -> pinned staging             */
     double unpack_ms;           /* staged form, calling thread: pinned staging -> caller's out (its share of the chunks) */
     double unpack_helper_ms;    /* staged form, unpacking thread: the same for the other chunks              */
@@ -242,9 +248,13 @@ typedef struct irb_convolve_profile {
     double mac_ms;              /* device: the multiply-accumulate (direct form; -1 in the staged form)     */
     double fft_out_ms;          /* device: inverse FFTs + overlap-add of all blocks, written to the caller's buffer / the staging */
     double device_ms;           /* device: first forward-FFT launch -> last inverse-FFT launch done          */
-    int direct;                 /* 1: the kernels read / wrote the caller's (registered) memory; 0: staged copies */
+    int direct;                 /* 1: the kernels read / wrote the caller's (HIP host, or opt-in registered) memory; 0: staged copies */
     int chunks, blocks_per_chunk, pieces, steps;   /* steps = floor(La/B) + P (+1 without the reference's dropped tail); pieces = multiplies */
     int helper_thread, engine_created, mac_on_matrix_cores, mac_launches;
+    double pack_helper_ms;      /* (fields from here on: appended in round 5) staged form, helper threads: caller's audio / IR -> pinned staging (their sum) */
+    int registered_ranges;      /* direct form: ranges of pageable memory registered for the call (0 unless IRB_OFFLINE_DIRECT=1) */
+    int threads;                /* host threads that worked on the call (1 = the caller alone)                */
+    int in_chunks;              /* staged form: input chunks (forward-FFT launches); `chunks` counts the output chunks */
 } irb_convolve_profile;
 int  irb_convolve_last_profile(irb_convolve_profile *out);
 /* switch the device-event part of the profile on / off for the whole process; returns the previous setting (measurement

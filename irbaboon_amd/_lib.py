@@ -39,7 +39,8 @@ class ConvolveProfile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("total_ms", "setup_ms", "register_ms", "pack_ms", "unpack_ms", "unpack_helper_ms", "wait_ms", "wait_helper_ms",
                                           "stall_ms", "fft_in_ms", "mac_ms", "fft_out_ms", "device_ms")] + \
                [(n, C.c_int) for n in ("direct", "chunks", "blocks_per_chunk", "pieces", "steps", "helper_thread", "engine_created",
-                                       "mac_on_matrix_cores", "mac_launches")]
+                                       "mac_on_matrix_cores", "mac_launches")] + \
+               [("pack_helper_ms", C.c_double), ("registered_ranges", C.c_int), ("threads", C.c_int), ("in_chunks", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -69,6 +69,10 @@ struct irb_lfft {
     // of the last (bins, Hz per bin, octave fraction) are kept
     float *h_log = nullptr, *h_mean = nullptr, *d_hlog = nullptr, *d_hmean = nullptr;
     SmoothWindows *win = nullptr;
+    // convolveNonPeriodic's pinned staging [max_batch][N] (created by its first staged call on this plan) and the events behind its
+    // download chunks
+    float *h_stage = nullptr;
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -254,6 +258,8 @@ void irb_lfft_destroy(irb_lfft *p)
     (void) hipFree(p->d_w0); (void) hipFree(p->d_w1); (void) hipFree(p->d_time); (void) hipFree(p->d_spec);
     if (p->h_log) (void) hipHostFree(p->h_log);
     if (p->h_mean) (void) hipHostFree(p->h_mean);
+    if (p->h_stage) (void) hipHostFree(p->h_stage);
+    for (auto &e : p->ev_chunk) if (e) (void) hipEventDestroy(e);
     free_windows(p->win);
     for (auto &e : p->ev) if (e) (void) hipEventDestroy(e);
     if (p->stream) (void) hipStreamDestroy(p->stream);
@@ -781,6 +787,8 @@ int irb_sweep_lin_fadeout(double *sweep, int n, int index)
 }
 
 // ---- convolution::convolveNonPeriodic (fp/convolution.cpp:246-347) ------------------------------------
+void irb_copy_stream_(void *dst, const void *src, size_t bytes);   // host_copy.cpp
+
 int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch, int La,
                              const float *const *ir, int ir_ch, int Lh, float *const *out)
 {
@@ -802,36 +810,41 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
     irb_lfft *p = nullptr;
     int rc = cached_plan(device, N, batch, &p);
     if (rc != IRB_OK) { clear_out(); return rc; }
-    // ---- direct form (like irb_convolve_periodic's): the caller's audio, IR and result buffers are registered with the runtime for the
-    // call, the copy engine moves the samples straight between them and the device (zero padding = one device memset), no host
-    // copy at all.  Not for the stereo-IR-to-mono-audio layout (its average is taken on the host below) and not when the runtime
-    // refuses a registration: the staged form below serves then.
-    const char *env_direct = std::getenv("IRB_NONPERIODIC_DIRECT");   // (0: the staged form, for A/B and tests)
-    const bool want_direct = !(env_direct && env_direct[0] == '0');
-    if (want_direct && !(ir_ch == 2 && audio_ch == 1)) {
-        (void) irb_device_quiet_begin(device);                        // registration is a device-wide operation for the runtime (irb_fdl.h)
-        struct Quiet { int d; ~Quiet() { (void) irb_device_quiet_end(d); } } quiet{device};
+    // the device side, the same for both forms: zero padding = one device memset in front of the uploads, then transform, multiply, inverse
+    const int nbins = N / 2 + 1;
+    auto multiply_and_invert = [&]() -> int {
+        int r = irb_lfft_forward_device(p, p->d_time, p->d_spec, batch);
+        for (int c = 0; c < audio_ch && r == IRB_OK; c++) {
+            const int irc = (ir_rows == 2) ? c : 0;                   // :318-323
+            irb::k_cmul<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
+                reinterpret_cast<float2 *>(p->d_spec + (size_t) c * 2 * N),
+                reinterpret_cast<const float2 *>(p->d_spec + (size_t) (audio_ch + irc) * 2 * N), nbins);
+        }
+        hipError_t e;
+        if (r == IRB_OK && (e = hipGetLastError()) != hipSuccess) r = failf(IRB_ERR_HIP, "%s: %s", "k_cmul", hipGetErrorString(e));
+        if (r == IRB_OK) r = irb_lfft_inverse_device(p, p->d_spec, p->d_time, audio_ch);
+        return r;
+    };
+    // ---- direct form (like irb_convolve_periodic's): the copy engine moves the samples straight between the caller's buffers and the
+    // device, no host copy at all.  ONLY for buffers that are HIP host memory already (irb_host_alloc, hipHostMalloc, registered by
+    // the caller), or with IRB_OFFLINE_DIRECT=1, which registers pageable buffers for the call (exposure: INTEGRATION.md section 1).
+    // Not for the stereo-IR-to-mono-audio layout (its average is taken on the host below).
+    const DirectMode mode = direct_mode_from_env();
+    if (mode != DirectMode::kNever && !(ir_ch == 2 && audio_ch == 1)) {
+        struct Quiet { int d; bool on; ~Quiet() { if (on) (void) irb_device_quiet_end(d); } } quiet{device, false};
+        if (mode == DirectMode::kRegister) { (void) irb_device_quiet_begin(device); quiet.on = true; }   // registration is a device-wide operation for the runtime (irb_fdl.h)
         HostRanges ranges;
         ranges.add(audio, audio_ch, (size_t) La);
         ranges.add(ir, ir_rows, (size_t) Lh);
         ranges.add(out, audio_ch, (size_t) Lout);
-        if (ranges.commit()) {
+        if (ranges.commit(mode == DirectMode::kRegister)) {
             hipError_t e = hipMemsetAsync(p->d_time, 0, sizeof(float) * (size_t) batch * N, p->stream);
             for (int c = 0; c < audio_ch && e == hipSuccess; c++)
                 e = hipMemcpyAsync(p->d_time + (size_t) c * N, audio[c], sizeof(float) * (size_t) La, hipMemcpyHostToDevice, p->stream);
             for (int r = 0; r < ir_rows && e == hipSuccess; r++)
                 e = hipMemcpyAsync(p->d_time + (size_t) (audio_ch + r) * N, ir[r], sizeof(float) * (size_t) Lh, hipMemcpyHostToDevice, p->stream);
             if (e != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "upload", hipGetErrorString(e));
-            if (rc == IRB_OK) rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, batch);
-            const int nbins = N / 2 + 1;
-            for (int c = 0; c < audio_ch && rc == IRB_OK; c++) {
-                const int irc = (ir_rows == 2) ? c : 0;               // :318-323
-                irb::k_cmul<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
-                    reinterpret_cast<float2 *>(p->d_spec + (size_t) c * 2 * N),
-                    reinterpret_cast<const float2 *>(p->d_spec + (size_t) (audio_ch + irc) * 2 * N), nbins);
-            }
-            if (rc == IRB_OK && (e = hipGetLastError()) != hipSuccess) rc = failf(IRB_ERR_HIP, "%s: %s", "k_cmul", hipGetErrorString(e));
-            if (rc == IRB_OK) rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, audio_ch);
+            if (rc == IRB_OK) rc = multiply_and_invert();
             for (int c = 0; c < audio_ch && rc == IRB_OK; c++)        // :340-344: the first La + Lh - 1 samples
                 if ((e = hipMemcpyAsync(out[c], p->d_time + (size_t) c * N, sizeof(float) * (size_t) Lout, hipMemcpyDeviceToHost, p->stream)) != hipSuccess)
                     rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e));
@@ -843,61 +856,52 @@ int irb_convolve_nonperiodic(int device, const float *const *audio, int audio_ch
         }
         ranges.release();
     }
-    clear_out();
+    // ---- staged form (the default for pageable buffers): through the plan's pinned staging.  Every row is copied there and its
+    // upload enqueued at once, so the copy engine moves row k while the host copies row k + 1; the result comes back in chunks of
+    // ~1 MiB, each copied out to the caller's buffer (streaming stores) while the next is still on the link.
     do {
-        std::vector<float> host((size_t) batch * N, 0.0f);
-        for (int c = 0; c < audio_ch; c++) std::memcpy(&host[(size_t) c * N], audio[c], sizeof(float) * (size_t) La);
-        for (int r = 0; r < ir_rows; r++) std::memcpy(&host[(size_t) (audio_ch + r) * N], ir[r], sizeof(float) * (size_t) Lh);
-        if (ir_ch == 2 && audio_ch == 1) {                            // tools::sumToMono, fp/tools.cpp:25-28
-            float *p0 = &host[(size_t) audio_ch * N];
-            for (int i = 0; i < Lh; i++) { p0[i] += ir[1][i]; p0[i] /= 2.0f; }
+        hipError_t e = hipSuccess;
+        if (!p->h_stage) {
+            e = hipHostMalloc(reinterpret_cast<void **>(&p->h_stage), sizeof(float) * (size_t) p->max_batch * N);
+            for (auto &ev : p->ev_chunk) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "pinned staging", hipGetErrorString(e)); break; }
         }
-        hipError_t e = hipMemcpyAsync(p->d_time, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, p->stream);
+        e = hipMemsetAsync(p->d_time, 0, sizeof(float) * (size_t) batch * N, p->stream);
+        for (int c = 0; c < audio_ch && e == hipSuccess; c++) {
+            float *row = p->h_stage + (size_t) c * N;
+            std::memcpy(row, audio[c], sizeof(float) * (size_t) La);
+            e = hipMemcpyAsync(p->d_time + (size_t) c * N, row, sizeof(float) * (size_t) La, hipMemcpyHostToDevice, p->stream);
+        }
+        for (int r = 0; r < ir_rows && e == hipSuccess; r++) {
+            float *row = p->h_stage + (size_t) (audio_ch + r) * N;
+            std::memcpy(row, ir[r], sizeof(float) * (size_t) Lh);
+            if (ir_ch == 2 && audio_ch == 1)                          // tools::sumToMono, fp/tools.cpp:25-28
+                for (int i = 0; i < Lh; i++) { row[i] += ir[1][i]; row[i] /= 2.0f; }
+            e = hipMemcpyAsync(p->d_time + (size_t) (audio_ch + r) * N, row, sizeof(float) * (size_t) Lh, hipMemcpyHostToDevice, p->stream);
+        }
         if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "upload", hipGetErrorString(e)); break; }
-        rc = irb_lfft_forward_device(p, p->d_time, p->d_spec, batch);
+        rc = multiply_and_invert();
         if (rc != IRB_OK) break;
-        const int nbins = N / 2 + 1;
-        for (int c = 0; c < audio_ch; c++) {
-            const int irc = (ir_rows == 2) ? c : 0;                   // :318-323
-            irb::k_cmul<<<dim3((nbins + 255) / 256), dim3(256), 0, p->stream>>>(
-                reinterpret_cast<float2 *>(p->d_spec + (size_t) c * 2 * N),
-                reinterpret_cast<const float2 *>(p->d_spec + (size_t) (audio_ch + irc) * 2 * N), nbins);
+        // :340-344: the first La + Lh - 1 samples of every channel, in at most 8 chunks over all channels
+        const int per_ch = std::max(1, 8 / audio_ch);
+        const long chunk = std::max<long>(((Lout + per_ch - 1) / per_ch + 63) / 64 * 64, 1 << 16);
+        struct Piece { int c; long off, n; };
+        Piece pieces[8];
+        int np = 0;
+        for (int c = 0; c < audio_ch && e == hipSuccess; c++)
+            for (long off = 0; off < Lout && e == hipSuccess && np < 8; off += chunk) {
+                const long n = std::min<long>(chunk, Lout - off);
+                e = hipMemcpyAsync(p->h_stage + (size_t) c * N + off, p->d_time + (size_t) c * N + off, sizeof(float) * (size_t) n, hipMemcpyDeviceToHost, p->stream);
+                if (e == hipSuccess) e = hipEventRecord(p->ev_chunk[np], p->stream);
+                pieces[np++] = {c, off, n};
+            }
+        for (int k = 0; k < np && e == hipSuccess; k++) {
+            e = hipEventSynchronize(p->ev_chunk[k]);
+            if (e == hipSuccess) irb_copy_stream_(out[pieces[k].c] + pieces[k].off, p->h_stage + (size_t) pieces[k].c * N + pieces[k].off, sizeof(float) * (size_t) pieces[k].n);
         }
-        if ((e = hipGetLastError()) != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "k_cmul", hipGetErrorString(e)); break; }
-        rc = irb_lfft_inverse_device(p, p->d_spec, p->d_time, audio_ch);
-        if (rc != IRB_OK) break;
-        e = hipMemcpyAsync(host.data(), p->d_time, sizeof(float) * (size_t) audio_ch * N, hipMemcpyDeviceToHost, p->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-        if (e != hipSuccess) { rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
-        for (int c = 0; c < audio_ch; c++) std::memcpy(out[c], &host[(size_t) c * N], sizeof(float) * (size_t) Lout);   // :340-344
+        if (e != hipSuccess) { (void) hipStreamSynchronize(p->stream); rc = failf(IRB_ERR_HIP, "%s: %s", "download", hipGetErrorString(e)); break; }
     } while (0);
-    return rc;
-}
-
-// ---- ir::IRtoRealFFTRaw (fp/ir.cpp:106-147) ------------------------------------------------------------
-// the fallback of irb_ir_to_real_fft_raw (fdl_engine.hip) when the caller's buffers cannot be registered: through a short-lived engine
-int irb_ir_to_real_fft_raw_engine_(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows)
-{
-    if (!ir || !out || len < 1) return irb_set_error_(IRB_ERR_ARG, "bad argument");
-    if (!is_pow2(ir_part_size) || ir_part_size < 16 || ir_part_size > 2048)
-        return irb_set_error_(IRB_ERR_ARG, "irPartSize must be a power of two in [16, 2048]");
-    const int bufcount = len / ir_part_size + 1;                      // :107
-    const int N = ir_part_size * 2;                                   // :108
-    if ((long) out_len < (long) bufcount * N) return irb_set_error_(IRB_ERR_ARG, "out too small");
-    std::memset(out, 0, sizeof(float) * (size_t) bufcount * N);       // an untouched last buffer stays zero
-    irb_fdl_config cfg;
-    std::memset(&cfg, 0, sizeof cfg);
-    cfg.device = device; cfg.n_instances = 1; cfg.channels = 1; cfg.block = ir_part_size; cfg.max_ir_len = len;
-    cfg.max_blocks_per_call = 1;
-    irb_fdl *h = nullptr;
-    int rc = irb_fdl_create(&cfg, &h);
-    if (rc != IRB_OK) return rc;
-    const float *irp[1] = {ir};
-    rc = irb_fdl_set_ir(h, 0, irp, 1, len);
-    const int np = (len + ir_part_size - 1) / ir_part_size;
-    if (rc == IRB_OK) rc = irb_fdl_get_ir_spectra(h, 0, 0, out, np);
-    irb_fdl_destroy(h);
-    if (rc == IRB_OK && n_rows) *n_rows = bufcount;
+    if (rc != IRB_OK) clear_out();
     return rc;
 }
 

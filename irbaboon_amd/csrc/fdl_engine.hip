@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -120,6 +121,10 @@ struct irb_fdl {
     float *d_hio = nullptr, *d_hir = nullptr;   // device addresses of h_io / h_ir
     int *h_set_of_stream = nullptr, *h_np_of_set = nullptr;   // host: IR set of every stream, partitions in use of every set
     int2 *h_info = nullptr;                  // pinned staging of d_stream_info
+    // staged one-shot call (IRB_FDL_HOST_IO engines that take long calls): chunk-completion counters in device memory and the
+    // chunks' words in mapped host memory (one cache line each) that k_ifft_ola_run raises -- see StepArgs::ck_*
+    unsigned *d_ck = nullptr, *h_ck = nullptr, *d_hck = nullptr;
+    unsigned ck_seq = 0;
 };
 
 namespace {
@@ -175,6 +180,22 @@ int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
     return v ? std::atoi(v) : dflt;
+}
+
+// Internal knobs (tests, tools, A/B): ONE environment variable, IRB_DEBUG="name=value,name=value".  Not part of the interface;
+// the variables a user may set are listed in INTEGRATION.md.
+int dbg_int(const char *name, int dflt)
+{
+    const char *v = std::getenv("IRB_DEBUG");
+    if (!v) return dflt;
+    const size_t n = std::strlen(name);
+    for (const char *p = v; *p;) {
+        const char *e = std::strchr(p, ',');
+        const size_t len = e ? (size_t) (e - p) : std::strlen(p);
+        if (len > n && !std::strncmp(p, name, n) && p[n] == '=') return std::atoi(p + n + 1);
+        p += len + (e ? 1 : 0);
+    }
+    return dflt;
 }
 
 // One-block steps: which kernel family, and how a stream is spread over workgroups.
@@ -239,6 +260,7 @@ void choose_path(irb_fdl *h)
     if (!h->is_gfx950 && !std::getenv("IRB_COLS_HANDOFF")) h->cols_handoff = 1;
 }
 
+constexpr int kCkMax = 1024;                  // output chunks of a staged one-shot piece (irb_fdl::d_ck / h_ck)
 constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
 constexpr int kPadP = irb::kTilePeriod;       // H rows per set: P rounded up to this (a multiple of kTT); the extra rows stay zero
 
@@ -331,6 +353,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     for (int r = 0; r < 2; r++) { a.reg_nq[r] = 1; a.reg_off[r] = 0; }
     a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
+    a.ck_cnt = nullptr; a.ck_flag = nullptr; a.ck_blocks = 1; a.ck_seq = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -713,73 +736,204 @@ double now_ms()
     return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
-// The second host thread of a one-shot call: while the calling thread packs chunk c + 1 into pinned memory and enqueues it,
-// this one waits for chunk c - 1 and copies its samples out to the caller's buffer (the two host copies are most of a
-// call's time; on one thread they add up).  It sleeps on a condition variable between calls and makes no HIP call but
-// hipEventSynchronize / hipEventElapsedTime.
-struct Unpacker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<int(int)> job;                       // chunk -> IRB_* code; valid while `active`
-    std::atomic<int> enqueued{0}, unpacked{0}, limit{0}, rc{0};
-    bool active = false, quit = false;
-    void run()
+// ---- the staged one-shot call's host pipeline ------------------------------------------------------------------------------
+// The caller's pageable audio and result never become device-visible (host_ranges.hpp): their samples pass through the engine's
+// own pinned staging.  Per piece (<= kOfflineMaxBlocks blocks of the signal):
+//   in   the audio goes into the staging in chunks of growing size (the first is small, so that the device starts pulling samples
+//        over PCIe a few microseconds into the call); every thread of the call claims chunks from one counter, the CALLING thread
+//        launches a chunk's forward FFTs as soon as it and all earlier chunks are packed; the IR's samples are one more item of
+//        that queue (copied into the pinned IR staging, then one launch transforms them there);
+//   mul  one multiply over all blocks of the piece;
+//   out  ONE launch of the inverse FFTs + overlap-add for the whole piece writes the output staging and raises a word in
+//        mapped host memory per chunk of ~128 KiB (StepArgs::ck_*); every thread claims chunks from a second counter, spins on
+//        the chunk's word and copies the chunk to the caller's buffer with streaming stores (host_copy.cpp).
+// The helpers are plain C++ threads that make no HIP call at all; they sleep on a condition variable between calls.  A piece's
+// state is reference-counted: a helper that wakes up after the piece is over finds nothing to claim and touches nothing of the call.
+extern "C" void irb_copy_stream_(void *dst, const void *src, size_t bytes);   // host_copy.cpp
+
+constexpr int kCrewMax = 8;                            // threads of a staged call, the caller included
+constexpr long kSpinLimitNs = 4000000000L;             // a chunk word that has not come after 4 s: the call fails (a kernel that never finished)
+
+struct StagedPiece {
+    // geometry
+    int C = 0, B = 0;
+    long stride = 0;                                   // floats between the channels of the staging
+    const float *audio[2] = {nullptr, nullptr};
+    float *out[2] = {nullptr, nullptr};
+    float *host_in = nullptr, *host_out = nullptr;
+    long p0 = 0, La = 0, lim = 0;                      // first block of the piece; samples of audio / of result the call has
+    // the IR's samples (first piece only): rows of ir_len floats each; whoever gets to it first copies them -- the helpers look
+    // here before anything else, the calling thread only once no audio is left to pack
+    const float *ir[2] = {nullptr, nullptr};
+    float *ir_stage[2] = {nullptr, nullptr};
+    long ir_len = 0;
+    int ir_rows = 0;
+    std::atomic<unsigned char> ir_claimed{1}, ir_done{1};          // (1 / 1: this piece carries no IR)
+    // in: the audio is PACKED in items of ~128 KiB per channel, claimed in order from one counter, and LAUNCHED in chunks of
+    // whole items (few, growing: every launch of the forward-FFT kernel pays a few microseconds of ramp-up on the PCIe link)
+    std::vector<int> item_first, item_count, item_chunk;          // blocks; the launch chunk an item belongs to
+    std::vector<int> in_first, in_count;                           // launch chunks, in blocks
+    std::unique_ptr<std::atomic<int>[]> chunk_left;                // items of the chunk not yet packed
+    std::atomic<int> pack_next{0};
+    // out
+    int T = 0, ck_blocks = 1, nout = 0;
+    volatile unsigned *words = nullptr;                // chunk k's word at words[16 k]
+    unsigned seq = 0;
+    std::atomic<int> unpack_next{0}, unpacked{0};
+    // a call that fails sets gave_up and waits for `active` (helpers inside helper()) to drain before it returns: nothing may touch the
+    // caller's buffers afterwards.  (Both seq_cst: a helper that enters late sees gave_up, one that entered earlier is waited for.)
+    std::atomic<int> gave_up{0}, active{0};
+    // per-thread time accounting (index 0 = the calling thread)
+    double pack_ms[kCrewMax] = {0}, unpack_ms[kCrewMax] = {0}, wait_ms[kCrewMax] = {0};
+
+    bool copy_ir(int who)                              // false: someone else has it
+    {
+        if (ir_claimed.exchange(1, std::memory_order_acq_rel)) return false;
+        const double t0 = now_ms();
+        for (int r = 0; r < ir_rows; r++) std::memcpy(ir_stage[r], ir[r], sizeof(float) * (size_t) ir_len);
+        ir_done.store(1, std::memory_order_release);
+        pack_ms[who] += now_ms() - t0;
+        return true;
+    }
+    bool pack_one(int who)                             // false: nothing left to claim
+    {
+        const int i = pack_next.fetch_add(1, std::memory_order_acq_rel);
+        if (i >= (int) item_first.size()) return false;
+        const double t0 = now_ms();
+        const long s0 = (p0 + item_first[(size_t) i]) * B, n = (long) item_count[(size_t) i] * B;
+        const long have = std::max<long>(0, std::min<long>(n, La - s0));   // the rest of the item is the flush: the kernel reads zeros for it (StepArgs::in_len)
+        for (int ch = 0; ch < C; ch++)
+            if (have > 0) std::memcpy(host_in + (size_t) ch * stride + (size_t) item_first[(size_t) i] * B, audio[ch] + s0, sizeof(float) * (size_t) have);
+        chunk_left[(size_t) item_chunk[(size_t) i]].fetch_sub(1, std::memory_order_acq_rel);
+        pack_ms[who] += now_ms() - t0;
+        return true;
+    }
+    void unpack_all(int who)
     {
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return active || quit; });
-                if (quit) return;
+            if (gave_up.load()) return;
+            const int k = unpack_next.fetch_add(1, std::memory_order_acq_rel);
+            if (k >= nout) return;
+            const double t0 = now_ms();
+            volatile unsigned *w = words + 16 * (size_t) k;
+            timespec ts0;
+            clock_gettime(CLOCK_MONOTONIC, &ts0);
+            for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; spins++) {
+                __builtin_ia32_pause();
+                if (gave_up.load(std::memory_order_relaxed)) break;
+                if ((spins & 4095u) == 4095u) {
+                    timespec ts1;
+                    clock_gettime(CLOCK_MONOTONIC, &ts1);
+                    if ((ts1.tv_sec - ts0.tv_sec) * 1000000000L + (ts1.tv_nsec - ts0.tv_nsec) > kSpinLimitNs) { gave_up.store(1); break; }
+                }
             }
-            for (int c = 0; c < limit.load(std::memory_order_acquire); c++) {
-                while (enqueued.load(std::memory_order_acquire) <= c && c < limit.load(std::memory_order_acquire)) __builtin_ia32_pause();
-                if (c >= limit.load(std::memory_order_acquire)) break;
-                const int r = job(c);
-                if (r != IRB_OK) rc.store(r);
-                unpacked.store(c + 1, std::memory_order_release);
+            const double t1 = now_ms();
+            if (!gave_up.load(std::memory_order_relaxed)) {
+                const int first = k * ck_blocks, cnt = std::min(ck_blocks, T - first);
+                const long s0 = (p0 + first) * B, n = (long) cnt * B;
+                const long take = std::max<long>(0, std::min<long>(n, lim - s0));
+                for (int ch = 0; ch < C; ch++)
+                    if (take > 0) irb_copy_stream_(out[ch] + s0, host_out + (size_t) ch * stride + (size_t) first * B, sizeof(float) * (size_t) take);
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                active = false;
-            }
-            cv.notify_all();
+            wait_ms[who] += t1 - t0;
+            unpack_ms[who] += now_ms() - t1;
+            unpacked.fetch_add(1, std::memory_order_acq_rel);
         }
     }
-    void begin(int nc, std::function<int(int)> f)
+    void helper(int who)
     {
-        if (!th.joinable()) th = std::thread([this] { run(); });
-        job = std::move(f);
-        enqueued.store(0); unpacked.store(0); rc.store(0); limit.store(nc);
-        { std::lock_guard<std::mutex> lk(mu); active = true; }
-        cv.notify_all();
+        active.fetch_add(1);
+        if (!gave_up.load()) {
+            (void) copy_ir(who);
+            while (!gave_up.load() && pack_one(who)) { }
+            unpack_all(who);
+        }
+        active.fetch_sub(1);
     }
-    int finish()                                       // after the last post (or after lowering `limit`): wait for the worker to go idle
+    void abandon()                                     // the call has failed: no helper is inside this piece when this returns
     {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !active; });
-        job = nullptr;
-        return rc.load();
+        gave_up.store(1);
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0; active.load() > 0; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 4095u) == 4095u) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2 * kSpinLimitNs) break;
+            }
+        }
+    }
+};
+
+struct Crew {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::shared_ptr<StagedPiece> cur;
+    std::atomic<unsigned long long> gen{0};
+    bool quit = false;
+    long linger_ns = 150000;                           // a helper that has finished a piece keeps looking for the next one this long before it
+                                                       // sleeps: calls in a row (a batch render) do not pay a thread wake-up each (~40 us)
+    void run(int who)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::shared_ptr<StagedPiece> p;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || gen.load(std::memory_order_acquire) != seen; });
+                if (quit) return;
+                seen = gen.load(std::memory_order_acquire);
+                p = cur;
+            }
+            if (p) p->helper(who);
+            p.reset();
+            timespec t0;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (unsigned spins = 0; gen.load(std::memory_order_acquire) == seen; spins++) {
+                __builtin_ia32_pause();
+                if ((spins & 255u) == 255u) {
+                    timespec t1;
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > linger_ns) break;
+                }
+            }
+        }
+    }
+    int ensure(int n)                                  // helpers that exist afterwards (<= n)
+    {
+        n = std::min(n, kCrewMax - 1);
+        try {
+            while ((int) th.size() < n) { const int who = (int) th.size() + 1; th.emplace_back([this, who] { run(who); }); }
+        } catch (...) { }                              // no more threads to be had: the caller works with the ones there are
+        return (int) th.size();
+    }
+    void post(std::shared_ptr<StagedPiece> p)
+    {
+        { std::lock_guard<std::mutex> lk(mu); cur = std::move(p); gen.fetch_add(1, std::memory_order_acq_rel); }
+        cv.notify_all();
     }
     void stop()
     {
-        if (!th.joinable()) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        if (th.empty()) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cur.reset(); }
         cv.notify_all();
-        th.join();
+        for (auto &t : th) t.join();
+        th.clear();
         quit = false;
     }
 };
 
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
-    std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing); [4 + k]: output chunk k has left (staged form)
-    Unpacker unpacker;
+    std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing)
+    Crew crew;
     irb_convolve_profile prof;
     bool have_prof = false;
     void release()
     {
-        unpacker.stop();
+        crew.stop();
         if (!eng) return;
         DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
         (void) hipSetDevice(eng->device);
@@ -793,7 +947,6 @@ struct OfflineEngineGuard {
 };
 thread_local OfflineEngineGuard g_offline;
 std::atomic<bool> g_offline_profile_events{false};     // irb_convolve_profile_events(): read the chunks' device events into the profile
-constexpr int kOfflineChunk = 1024;                       // blocks per input / output chunk of irb_convolve_periodic (IRB_OFFLINE_CHUNK); profiles/r04_oneshot_sweep.txt
 constexpr int kOfflineMaxBlocks = 16384;                  // blocks per multiply: longer signals go through in several (the FDL carries over)
 }
 
@@ -817,6 +970,8 @@ void irb_fdl_destroy(irb_fdl *h)
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
     if (h->h_status) (void) hipHostFree(h->h_status);
     if (h->h_done) (void) hipHostFree(h->h_done);
+    if (h->h_ck) (void) hipHostFree(h->h_ck);
+    (void) hipFree(h->d_ck);
     if (h->bar_in) (void) hipFree(h->bar_in);
     if (h->rt_stream) (void) hipStreamDestroy(h->rt_stream);
     if (h->h_io) (void) hipHostFree(h->h_io);
@@ -947,6 +1102,16 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         }
         *h->h_status = 0;
         *h->h_done = 0;
+        if (h->host_io && !h->stepwise) {                 // the one-shot function's engine
+            if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ck), sizeof(unsigned) * 16 * kCkMax, hipHostMallocMapped)) != hipSuccess ||
+                (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hck), h->h_ck, 0)) != hipSuccess ||
+                (e = hipMalloc(reinterpret_cast<void **>(&h->d_ck), sizeof(unsigned) * kCkMax)) != hipSuccess ||
+                (e = hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * kCkMax, h->stream)) != hipSuccess) {
+                rc = fail(IRB_ERR_HIP, "chunk words: %s", hipGetErrorString(e));
+                break;
+            }
+            std::memset(h->h_ck, 0, sizeof(unsigned) * 16 * kCkMax);
+        }
         if (h->host_io && h->stepwise && env_int("IRB_RT_BAR", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
@@ -1579,8 +1744,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     const double t_begin = now_ms();
     irb_convolve_profile prof;
     std::memset(&prof, 0, sizeof prof);
-    const int io = std::max(16, (env_int("IRB_OFFLINE_CHUNK", kOfflineChunk) + 15) / 16 * 16);   // multiple of the FFT kernels' blocks per workgroup
-    const int Tneed = (int) std::min<long>(steps, std::max(2, env_int("IRB_OFFLINE_MAX_BLOCKS", kOfflineMaxBlocks)));   // (override: tests run several pieces on small signals)
+    const int Tneed = (int) std::min<long>(steps, std::max(2, dbg_int("offline_max_blocks", kOfflineMaxBlocks)));   // (override: tests run several pieces on small signals)
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     irb_fdl *h = g_offline.eng;
@@ -1592,76 +1756,98 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         cfg.max_blocks_per_call = Tneed < 512 ? Tneed : (Tneed + 1023) / 1024 * 1024;   // (a later call of this block size and IR length that is a little longer still fits)
         cfg.flags = IRB_FDL_HOST_IO;
         int rc0 = irb_fdl_create(&cfg, &h);
-        if (rc0 != IRB_OK) return rc0;
+        if (rc0 != IRB_OK) { clear_out(0); return rc0; }
         g_offline.eng = h;
         hipError_t e = hipSuccess;
-        g_offline.ev.assign((size_t) 4 + (h->Tmax + 15) / 16, nullptr);          // (created on first use)
+        g_offline.ev.assign(4, nullptr);
         for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
-        if (e != hipSuccess) { g_offline.release(); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { g_offline.release(); clear_out(0); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
     OfflineEngineGuard &g = g_offline;
-    int rc = irb_fdl_reset(h);
-    if (rc != IRB_OK) return rc;
-    // The IR's set-up (partition FFTs straight out of the pinned staging, zero rows, the tap-contiguous copy for the matrix cores, the
-    // stream records: four short device operations, ~20 us) goes on the engine's own stream BEHIND the first forward-FFT launch:
-    // the device does not overlap the two anyway (rocprofv3 timeline, profiles/r04_oneshot_timeline.txt: on a second stream the
-    // set-up's kernels started when the forward FFTs' workgroups retired, and the join in front of the multiply cost another
-    // ~20 us of idle device), and the HOST part -- the IR's samples copied into pinned staging, 0.1 ms for a 10-second stereo IR --
-    // now happens while the device already pulls the audio over PCIe.
-    bool ir_started = false;
-    auto start_ir = [&]() -> int {
-        if (ir_started) return IRB_OK;
-        ir_started = true;
-        return irb_fdl_set_ir(h, 0, ir, ir_ch, Lh_eff);
+    // every error return from here on: nothing of the call may still be reading the staging or writing the result, and the result
+    // is the cleared buffer the reference returns when it gives up (:39-42) -- never a half-written one
+    std::shared_ptr<StagedPiece> live;                                  // the piece the helper threads may be working on
+    auto bail = [&](int code) {
+        char keep[sizeof g_err];
+        std::memcpy(keep, g_err, sizeof keep);
+        if (live) live->abandon();
+        (void) irb_sync(h);
+        if (h->d_ck) { (void) hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * kCkMax, h->stream); (void) irb_sync(h); }   // (a piece that died half-way leaves counts behind)
+        clear_out(0);
+        std::memcpy(g_err, keep, sizeof keep);
+        return code;
     };
-    // every path below calls this in front of its multiply
-    auto join_ir = [&]() -> int { return start_ir(); };
-    // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves (both registered for the
-    // call): no host copy at all, one launch per phase.  Taken unless registration is refused (then the staged pipeline below runs).
-    bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
-    if (env_int("IRB_OFFLINE_DIRECT", 1) != 0 && steps >= 2 && !last_piece_is_one_block) {
+    int rc = IRB_OK;
+    const bool device_times = g_offline_profile_events;
+    // The IR's set-up is ONE launch that transforms the samples where they lie (k_ir_fft_direct: partition FFTs, zero rows, stream
+    // records) + the tap-contiguous copy for the matrix cores.  "Where they lie" is the engine's pinned IR staging unless the caller's IR
+    // is device-visible itself (direct form).  It goes on the engine's stream BEHIND the first forward-FFT launch: the device does
+    // not overlap the two anyway (profiles/r04_oneshot_timeline.txt), and the host's copy of the IR into the staging then happens
+    // while the device already pulls audio over PCIe.
+    bool ir_started = false;
+    float *ir_stage[2] = {h->h_ir, h->h_ir + (size_t) h->P * h->B};             // (h_ir holds 2 C P B floats: two rows of any IR this engine takes)
+    const float *ir_stage_dev[2] = {h->d_hir, h->d_hir + (size_t) h->P * h->B};
+    auto launch_ir_from_staging = [&]() -> int { ir_started = true; return set_ir_direct(h, ir_stage_dev, ir_ch, Lh_eff); };
+    auto ir_now = [&]() -> int {                                                   // copy + launch on the calling thread
+        if (ir_started) return IRB_OK;
+        for (int r = 0; r < ir_ch; r++) std::memcpy(ir_stage[r], ir[r], sizeof(float) * (size_t) Lh_eff);
+        return launch_ir_from_staging();
+    };
+    // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves: no host copy at all, one
+    // launch per phase.  ONLY for buffers that are HIP host memory already (irb_host_alloc / hipHostMalloc, or registered by the
+    // caller), or when the caller has opted in to the per-call registration of pageable memory (IRB_OFFLINE_DIRECT=1; exposure:
+    // INTEGRATION.md section 1, profiles/NOTES.md "Two wrong one-shot results").
+    const DirectMode mode = direct_mode_from_env();
+    const bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
+    if (mode != DirectMode::kNever && steps >= 2 && !last_piece_is_one_block) {
         const double t_reg = now_ms();
         // (registering and unregistering host memory are device-wide operations for the runtime: with a resident real-time server
-        // alive on the device the call waited until that server's callbacks stopped -- 0.44 s in tests' phase 2 -- so the whole direct
-        // form sits in a quiet section: servers step aside for its ~0.3 ms, their callbacks take the one-launch form meanwhile)
-        DeviceQuiet quiet(device);
-        HostRanges ranges;
-        float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
-        const float *d_irp[2] = {nullptr, nullptr};
-        // the impulse response too, when the runtime accepts its pages (a read-only mapping is refused: the staged set-up serves then)
-        bool ir_direct = env_int("IRB_OFFLINE_IR_DIRECT", 1) != 0 && Lh_eff > 0;
-        ranges.add(audio, audio_ch, (size_t) La);
-        ranges.add(out, audio_ch, (size_t) Lout);
-        if (ir_direct) ranges.add(ir, ir_ch, (size_t) Lh_eff);
-        bool ok = ranges.commit();
-        if (!ok && ir_direct) {
-            ranges.release();
-            ir_direct = false;
+        // alive on the device the call waited until that server's callbacks stopped, so the registering form sits in a quiet section)
+        std::unique_ptr<DeviceQuiet> quiet;
+        HostRanges ranges, ir_ranges;
+        bool ok = false, ir_direct = false;
+        if (mode == DirectMode::kRegister) {
+            quiet.reset(new DeviceQuiet(device));
             ranges.add(audio, audio_ch, (size_t) La);
             ranges.add(out, audio_ch, (size_t) Lout);
-            ok = ranges.commit();
+            ranges.add(ir, ir_ch, (size_t) Lh_eff);
+            ok = ir_direct = ranges.commit(true);
+            if (!ok) {                                               // (a read-only mapping of the IR is refused: the staged set-up serves then)
+                ranges.release();
+                ranges.add(audio, audio_ch, (size_t) La);
+                ranges.add(out, audio_ch, (size_t) Lout);
+                ok = ranges.commit(true);
+            }
+        } else {
+            ranges.add(audio, audio_ch, (size_t) La);
+            ranges.add(out, audio_ch, (size_t) Lout);
+            ok = ranges.commit(false);
+            if (ok) { ir_ranges.add(ir, ir_ch, (size_t) Lh_eff); ir_direct = ir_ranges.commit(false); }
         }
+        float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
+        const float *d_irp[2] = {nullptr, nullptr};
         for (int c = 0; c < audio_ch && ok; c++) {
             d_audio[c] = ranges.dev(audio[c]);
             d_res[c] = ranges.dev(out[c]);
             ok = d_audio[c] && d_res[c];
         }
         for (int c = 0; c < ir_ch && ok && ir_direct; c++) {
-            d_irp[c] = ranges.dev(ir[c]);
+            d_irp[c] = (mode == DirectMode::kRegister ? ranges : ir_ranges).dev(ir[c]);
             if (!d_irp[c]) ir_direct = false;
         }
         const long in_stride = audio_ch == 2 && ok ? (long) (d_audio[1] - d_audio[0]) : 0, out_stride = audio_ch == 2 && ok ? (long) (d_res[1] - d_res[0]) : 0;
         if (ok) {
             prof.register_ms = now_ms() - t_reg;
             prof.setup_ms = t_reg - t_begin;
-            const bool device_times = g_offline_profile_events;
+            prof.registered_ranges = ranges.n_registered;
+            rc = irb_fdl_reset(h);
+            if (rc != IRB_OK) { (void) irb_sync(h); ranges.release(); ir_ranges.release(); return bail(rc); }
             float dev_ms[4] = {0, 0, 0, 0};
             int pieces = 0, mac_launches = 1;
             if (ir_direct) {
                 // the IR transformed where it lies, in FRONT of the forward FFTs: both pull their samples over PCIe, so one after the other
                 // costs the link's time once, and nothing of the IR's set-up is left between the forward FFTs and the multiply
-                // (rocprofv3 timelines in profiles/NOTES.md: behind them it was 27 us of device time + two gaps)
                 if (device_times) (void) hipEventRecord(g.ev[0], h->stream);   // (the profile counts it with the forward FFTs: "in")
                 rc = set_ir_direct(h, d_irp, ir_ch, Lh_eff);
                 ir_started = true;
@@ -1679,7 +1865,7 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
                 if (device_times && !(ir_direct && pieces == 0)) (void) hipEventRecord(g.ev[0], h->stream);
                 rc = tiled_push(h, call, 0, T);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
-                if (rc == IRB_OK) rc = join_ir();                            // (the first piece starts the IR's set-up here, behind its forward FFTs)
+                if (rc == IRB_OK) rc = ir_now();                             // (an IR that is not device-visible: through the staging, behind the first piece's forward FFTs)
                 if (rc == IRB_OK) rc = tiled_mac(h, call);
                 if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
                 if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
@@ -1700,129 +1886,196 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             const hipError_t e = irb_sync(h);                        // also on failure: nothing may still be reading or writing the caller's memory
             prof.wait_ms = now_ms() - t_wait;
             ranges.release();
-            if (rc != IRB_OK) return rc;
-            if (e != hipSuccess) return fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e));
+            ir_ranges.release();
+            if (rc != IRB_OK) return bail(rc);
+            if (e != hipSuccess) return bail(fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e)));
             rc = check_status(h);
-            if (rc != IRB_OK) return rc;
+            if (rc != IRB_OK) return bail(rc);
             prof.total_ms = now_ms() - t_begin;
             prof.direct = 1;
             prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
             prof.device_ms = device_times ? dev_ms[3] : -1.0;
             prof.chunks = pieces; prof.blocks_per_chunk = Tneed; prof.pieces = pieces; prof.steps = (int) steps;
             prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
-            {
-                prof.mac_launches = prof.mac_on_matrix_cores ? mac_launches : 1;
-            }
+            prof.mac_launches = prof.mac_on_matrix_cores ? mac_launches : 1;
+            prof.threads = 1;
             g.prof = prof; g.have_prof = true;
             return IRB_OK;
         }
-        ranges.release();                                            // registration refused (read-only mapping, exotic memory): staged copies
+        ranges.release();                                            // not HIP host memory (or a registration refused): the staged form
+        ir_ranges.release();
     }
 
-    rc = start_ir();                                                 // staged form: the calling thread is about to be busy packing
-    if (rc != IRB_OK) return rc;
+    // ---- staged form (the default for pageable buffers): see StagedPiece above
     const long stride = (long) h->Tmax * h->B;
     float *const host_in = h->h_io, *const host_out = h->h_io + (size_t) audio_ch * stride;
     float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
+    const int want_threads = std::max(1, std::min(kCrewMax, env_int("IRB_OFFLINE_THREADS", 3)));
+    const long call_bytes = (long) sizeof(float) * ((long) La + Lout) * audio_ch;
+    // (a helper needs tens of microseconds to wake up: calls that move less than a megabyte are over before it would have copied anything)
+    const int helpers = (want_threads > 1 && call_bytes >= dbg_int("offline_helpers_from", 1 << 20)) ? g.crew.ensure(want_threads - 1) : 0;
+    const int fixed_chunk = dbg_int("offline_chunk", 0);               // (tests: every item, launch chunk and output chunk this many blocks)
+    g.crew.linger_ns = 1000L * std::max(0, dbg_int("offline_linger_us", 150));
+    int ola_nb = 4;
+    FOR_N(h->N, ola_nb = irb::OlaGeom<NN>::NB);
+    bool ir_in_piece = false;
+    auto build_piece = [&](long p0, int T) {
+        auto pc = std::make_shared<StagedPiece>();
+        pc->C = audio_ch; pc->B = B; pc->stride = stride; pc->p0 = p0; pc->La = La; pc->lim = lim; pc->T = T;
+        for (int c = 0; c < audio_ch; c++) { pc->audio[c] = audio[c]; pc->out[c] = out[c]; }
+        pc->host_in = host_in; pc->host_out = host_out;
+        // launch chunks: ~256 KiB per channel first, then four times the one before; a remainder shorter than twice the next chunk joins it
+        // (multiples of 16 blocks: the forward-FFT kernels' workgroups).  Items: ~128 KiB per channel.
+        const int c0 = fixed_chunk > 0 ? (fixed_chunk + 15) / 16 * 16 : std::max(16, (65536 / B + 15) / 16 * 16);
+        const int it = fixed_chunk > 0 ? c0 : std::max(16, (32768 / B + 15) / 16 * 16);
+        for (int first = 0, c = c0; first < T; c = fixed_chunk > 0 ? c : 4 * c) {
+            const int cnt = (T - first < 2 * c && fixed_chunk == 0) ? T - first : std::min(c, T - first);
+            pc->in_first.push_back(first); pc->in_count.push_back(cnt);
+            first += cnt;
+        }
+        const int nin = (int) pc->in_first.size();
+        pc->chunk_left.reset(new std::atomic<int>[(size_t) nin]);
+        for (int k = 0; k < nin; k++) {
+            int n_items = 0;
+            for (int f = pc->in_first[(size_t) k], e = f + pc->in_count[(size_t) k]; f < e; f += it, n_items++) {
+                pc->item_first.push_back(f); pc->item_count.push_back(std::min(it, e - f)); pc->item_chunk.push_back(k);
+            }
+            pc->chunk_left[(size_t) k].store(n_items, std::memory_order_relaxed);
+        }
+        if (!ir_started && !ir_in_piece) {                               // the IR's samples travel with the first piece
+            ir_in_piece = true;
+            pc->ir_rows = ir_ch; pc->ir_len = Lh_eff;
+            for (int r = 0; r < ir_ch; r++) { pc->ir[r] = ir[r]; pc->ir_stage[r] = ir_stage[r]; }
+            pc->ir_done.store(0, std::memory_order_relaxed);
+            pc->ir_claimed.store(0, std::memory_order_release);
+        }
+        // output chunks: ~128 KiB per channel (multiples of the inverse-FFT kernel's blocks per workgroup), at most kCkMax
+        int ck = fixed_chunk > 0 ? fixed_chunk : std::max(ola_nb, 32768 / B);
+        ck = (ck + ola_nb - 1) / ola_nb * ola_nb;
+        while ((T + ck - 1) / ck > kCkMax) ck *= 2;
+        pc->ck_blocks = ck; pc->nout = (T + ck - 1) / ck;
+        pc->words = h->h_ck;
+        if (++h->ck_seq == 0) ++h->ck_seq;                                // (0 is the words' initial value)
+        pc->seq = h->ck_seq;
+        return pc;
+    };
+    // the first piece goes to the helpers BEFORE anything is asked of the device: they wake up (or, lingering from the call before, start at once) while
+    // this thread resets the FDL and packs the first chunk
+    std::shared_ptr<StagedPiece> first_piece;
+    {
+        const int T0 = (int) std::min<long>(Tneed, steps);
+        if (T0 > 1) { first_piece = live = build_piece(0, T0); if (helpers > 0) g.crew.post(first_piece); }
+    }
+    rc = irb_fdl_reset(h);
+    if (rc != IRB_OK) return bail(rc);
     prof.setup_ms = now_ms() - t_begin;
-    const bool device_times = g_offline_profile_events;
-    const bool want_helper = env_int("IRB_OFFLINE_HELPER", 1) != 0;
-    double pack_ms = 0, unpack_ms[2] = {0, 0}, wait_ms[2] = {0, 0}, dev_ms[3] = {0, 0, 0};
-    int pieces = 0, nio_total = 0;
+    double pack_ms[2] = {0, 0}, unpack_ms[2] = {0, 0}, wait_ms[2] = {0, 0}, dev_ms[3] = {0, 0, 0};   // [0] the calling thread, [1] the helpers' sum
+    int pieces = 0, nin_total = 0, nout_total = 0, last_ck = 0;
+    auto spin_timed_out = [](const timespec &t0) {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        return (t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > kSpinLimitNs;
+    };
 
     for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
         const int T = (int) std::min<long>(Tneed, steps - p0);
-        const int nio = (T + io - 1) / io;
-        nio_total += nio;
-        for (int k = 0; k < nio; k++)
-            if (!g.ev[4 + k]) {
-                hipError_t e = hipEventCreateWithFlags(&g.ev[4 + k], hipEventDisableTiming);
-                if (e != hipSuccess) return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e));
-            }
-        TiledCall call;
-        bool tiled = T > 1;
         irb::StepArgs a = step_args(h, dev_in, dev_out, stride);
-        if (tiled) { rc = tiled_begin(h, a, T, &call); if (rc != IRB_OK) break; }
-        if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
-        // ---- in: pack + forward FFTs, chunk by chunk
-        for (int k = 0; k < nio && rc == IRB_OK; k++) {
-            const int first = k * io, cnt = std::min(io, T - first);
-            const long s0 = (p0 + first) * B, n = (long) cnt * B;
-            const long have = std::max<long>(0, std::min<long>(n, (long) La - s0));      // samples of this chunk that hold audio; the rest is the flush
-            const double t0 = now_ms();
+        a.in_len = std::max<long>(0, (long) La - p0 * B);               // blocks past the audio's end are the flush: the kernels read zeros, not the staging
+        a.out_len = std::max<long>(0, lim - p0 * B);
+        if (T == 1) {
+            // a one-block piece (a signal shorter than a block with a one-partition IR, or a last piece of one block): a plain step
+            const long have = std::max<long>(0, std::min<long>(B, (long) La - p0 * B)), take = std::max<long>(0, std::min<long>(B, lim - p0 * B));
             for (int ch = 0; ch < audio_ch; ch++) {
-                float *dst = host_in + (size_t) ch * stride + (size_t) first * B;
-                if (have > 0) std::memcpy(dst, audio[ch] + s0, sizeof(float) * (size_t) have);
-                std::fill(dst + have, dst + n, 0.0f);
+                float *dst = host_in + (size_t) ch * stride;
+                if (have > 0) std::memcpy(dst, audio[ch] + p0 * B, sizeof(float) * (size_t) have);
+                std::fill(dst + have, dst + B, 0.0f);
             }
-            pack_ms += now_ms() - t0;
-            if (tiled) rc = tiled_push(h, call, first, cnt);
+            rc = ir_now();
+            if (rc == IRB_OK) rc = launch_step(h, a);
+            if (rc != IRB_OK) break;
+            h->t += 1;
+            const hipError_t e = irb_sync(h);
+            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e)); break; }
+            for (int ch = 0; ch < audio_ch; ch++)
+                if (take > 0) std::memcpy(out[ch] + p0 * B, host_out + (size_t) ch * stride, sizeof(float) * (size_t) take);
+            continue;
+        }
+        std::shared_ptr<StagedPiece> pc;
+        if (p0 == 0 && first_piece) pc = std::move(first_piece);
+        else { pc = live = build_piece(p0, T); if (helpers > 0) g.crew.post(pc); }
+        const int nin = (int) pc->in_first.size();
+        nin_total += nin; nout_total += pc->nout; last_ck = pc->ck_blocks;
+        TiledCall call;
+        rc = tiled_begin(h, a, T, &call);
+        if (rc != IRB_OK) break;
+        if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
+        // ---- in: launch every chunk's forward FFTs as soon as it and its predecessors are packed; pack when there is nothing to launch
+        timespec ts0;
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        unsigned spins = 0;
+        for (int launched = 0; rc == IRB_OK;) {
+            while (launched < nin && rc == IRB_OK && pc->chunk_left[(size_t) launched].load(std::memory_order_acquire) == 0) {
+                rc = tiled_push(h, call, pc->in_first[(size_t) launched], pc->in_count[(size_t) launched]);
+                launched++;
+            }
+            if (rc == IRB_OK && !ir_started && pc->ir_done.load(std::memory_order_acquire)) rc = launch_ir_from_staging();
+            if (rc != IRB_OK || (launched == nin && ir_started)) break;
+            if (pc->pack_one(0)) continue;
+            if (pc->copy_ir(0)) continue;                                  // (no audio left to claim: the IR, unless a helper has it)
+            __builtin_ia32_pause();                                        // a helper is still copying what comes next
+            if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) rc = fail(IRB_ERR_STATE, "one-shot pipeline: a packing thread never finished its chunk");
         }
         if (rc != IRB_OK) break;
-        // ---- the multiply; a one-block call (a signal shorter than a block with a one-partition IR) is a plain step
-        rc = join_ir();
-        if (rc != IRB_OK) break;
-        if (tiled) rc = tiled_mac(h, call);
-        else { rc = launch_step(h, a); if (rc == IRB_OK) h->t += 1; }
+        // ---- the multiply over all blocks of the piece
+        rc = tiled_mac(h, call);
         if (rc != IRB_OK) break;
         if (device_times) (void) hipEventRecord(g.ev[1], h->stream);
-        // ---- out: inverse FFTs + overlap-add chunk by chunk, an event behind each
-        for (int k = 0; k < nio && rc == IRB_OK; k++) {
-            const int first = k * io, cnt = std::min(io, T - first);
-            if (tiled) rc = tiled_ifft(h, call, first, cnt);
-            if (rc == IRB_OK && hipEventRecord(g.ev[4 + k], h->stream) != hipSuccess) rc = fail(IRB_ERR_HIP, "hipEventRecord failed");
-        }
-        if (device_times) (void) hipEventRecord(g.ev[2], h->stream);
-        if (tiled && rc == IRB_OK) tiled_end(h, call);
+        // ---- out: one launch; it raises the chunks' words as it goes
+        call.a.ck_cnt = h->d_ck; call.a.ck_flag = h->d_hck; call.a.ck_blocks = pc->ck_blocks; call.a.ck_seq = pc->seq;
+        rc = tiled_ifft(h, call, 0, T);
         if (rc != IRB_OK) break;
-        // ---- unpack: chunk k of this piece -> out, even k here, odd k on the unpacking thread
-        auto unpack = [&](int k, int who) -> int {
-            const double t0 = now_ms();
-            hipError_t e = hipEventSynchronize(g.ev[4 + k]);
-            if (e != hipSuccess) return fail(IRB_ERR_HIP, "waiting for an output chunk: %s", hipGetErrorString(e));
-            const double t1 = now_ms();
-            const int first = k * io, cnt = std::min(io, T - first);
-            const long s0 = (p0 + first) * B, n = (long) cnt * B;
-            const long take = std::max<long>(0, std::min<long>(n, lim - s0));
-            for (int ch = 0; ch < audio_ch; ch++)
-                if (take > 0) std::memcpy(out[ch] + s0, host_out + (size_t) ch * stride + (size_t) first * B, sizeof(float) * (size_t) take);
-            wait_ms[who] += t1 - t0;
-            unpack_ms[who] += now_ms() - t1;
-            return IRB_OK;
-        };
-        const bool helper = want_helper && nio >= 2;
-        if (helper) {
-            const int dev = device, n_odd = nio / 2;
-            g.unpacker.begin(n_odd, [&, dev](int i) { (void) hipSetDevice(dev); return unpack(2 * i + 1, 1); });
-            g.unpacker.enqueued.store(n_odd, std::memory_order_release);               // everything is enqueued already
+        if (device_times) (void) hipEventRecord(g.ev[2], h->stream);
+        tiled_end(h, call);
+        pc->unpack_all(0);
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        const double t_stall = now_ms();
+        for (spins = 0; pc->unpacked.load(std::memory_order_acquire) < pc->nout && !pc->gave_up.load(); ) {   // the chunks the helpers claimed
+            __builtin_ia32_pause();
+            if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) { pc->gave_up.store(1); break; }
         }
-        for (int k = 0; k < nio && rc == IRB_OK; k += helper ? 2 : 1) rc = unpack(k, 0);
-        if (helper) {
-            const double t0 = now_ms();
-            const int rcu = g.unpacker.finish();
-            prof.stall_ms += now_ms() - t0;
-            if (rc == IRB_OK && rcu != IRB_OK) rc = fail(rcu, "one-shot pipeline: waiting for an output chunk failed on the unpacking thread");
-            prof.helper_thread = 1;
+        prof.stall_ms += now_ms() - t_stall;
+        if (pc->gave_up.load()) {
+            // a chunk's word never came: a kernel of this piece did not finish.  Let the runtime say why, if it knows.
+            const hipError_t e = hipStreamSynchronize(h->stream);
+            rc = fail(e != hipSuccess ? IRB_ERR_HIP : IRB_ERR_STATE, "one-shot pipeline: an output chunk never arrived (%s)", e != hipSuccess ? hipGetErrorString(e) : "no device error reported");
+            break;
         }
-        if (rc == IRB_OK && device_times) {
+        pack_ms[0] += pc->pack_ms[0]; unpack_ms[0] += pc->unpack_ms[0]; wait_ms[0] += pc->wait_ms[0];
+        for (int w = 1; w < kCrewMax; w++) { pack_ms[1] += pc->pack_ms[w]; unpack_ms[1] += pc->unpack_ms[w]; wait_ms[1] += pc->wait_ms[w]; }
+        if (device_times) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;     // forward FFTs (incl. waiting for the host's packing) + multiply
-            if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;     // inverse FFTs + overlap-add
+            if (hipEventSynchronize(g.ev[2]) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;     // forward FFTs (incl. waiting for the host's packing) + multiply
+                if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;     // inverse FFTs + overlap-add
+            }
         }
     }
-    if (rc != IRB_OK) { (void) irb_sync(h); return rc; }          // nothing of a failed call may still be writing the staging
+    if (rc != IRB_OK) return bail(rc);
+    live.reset();
+    rc = check_status(h);
+    if (rc != IRB_OK) return bail(rc);
     prof.total_ms = now_ms() - t_begin;
-    prof.pack_ms = pack_ms; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1];
+    prof.pack_ms = pack_ms[0]; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1]; prof.pack_helper_ms = pack_ms[1];
     prof.wait_ms = wait_ms[0]; prof.wait_helper_ms = wait_ms[1];
     prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;   // (staged: the multiply is inside fft_in_ms)
     prof.device_ms = device_times ? dev_ms[0] + dev_ms[1] : -1.0;
-    prof.chunks = nio_total; prof.blocks_per_chunk = io; prof.pieces = pieces; prof.steps = (int) steps;
+    prof.chunks = nout_total; prof.in_chunks = nin_total; prof.blocks_per_chunk = last_ck; prof.pieces = pieces; prof.steps = (int) steps;
     prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
-    {
-        prof.mac_launches = prof.mac_on_matrix_cores ? mfma_plan(h, Tneed).n : 1;
-    }
+    prof.mac_launches = prof.mac_on_matrix_cores ? mfma_plan(h, Tneed).n : 1;
+    prof.helper_thread = helpers > 0 ? 1 : 0;
+    prof.threads = 1 + helpers;
     g.prof = prof; g.have_prof = true;
-    return rc;
+    return IRB_OK;
 }
 
 int irb_device_quiet_begin(int device)
@@ -1941,14 +2194,18 @@ int irb_fdl_multi_process(irb_fdl_multi *m, const float *const *in, float *const
 }
 
 // ---- ir::IRtoRealFFTRaw (fp/ir.cpp:106-147): an IR's partitions as packed spectra rows, the layout the reference's plug-in keeps
-// its IR in.  The rows are exactly what k_ir_fft_direct writes (bin 0 = (DC, Nyquist)), so: register the caller's IR and result
-// buffers, one launch transforms the IR where it lies into a small device buffer kept per thread, one copy brings the rows back.
+// its IR in.  The rows are exactly what k_ir_fft_direct writes (bin 0 = (DC, Nyquist)): one launch transforms the IR's samples
+// where they lie and writes the rows where the host reads them.  "Where they lie" / "where the host reads them" are the caller's own
+// buffers when those are HIP host memory (or with IRB_OFFLINE_DIRECT=1: registered for the call), otherwise -- the default for
+// pageable buffers, host_ranges.hpp -- a pinned staging pair kept per thread: one host copy in, one out.
 // (Until round 4 every call built and destroyed an engine: 4.9 ms for a 2-second IR; now ~0.1 ms.)
 namespace {
 struct RawPlan {
     int device = -1, N = 0;
-    size_t rows = 0;
+    size_t rows = 0, in_floats = 0;
     float2 *d_H = nullptr, *d_tw = nullptr;
+    float *h_in = nullptr, *h_out = nullptr;           // pinned, mapped: [in_floats], [rows * N]
+    float *d_hin = nullptr, *d_hout = nullptr;         // their device addresses
     hipStream_t stream = nullptr;
     void release()
     {
@@ -1957,14 +2214,14 @@ struct RawPlan {
         (void) hipSetDevice(device);
         if (stream) { (void) hipStreamSynchronize(stream); (void) hipStreamDestroy(stream); }
         (void) hipFree(d_H); (void) hipFree(d_tw);
-        d_H = d_tw = nullptr; stream = nullptr; device = -1; N = 0; rows = 0;
+        if (h_in) (void) hipHostFree(h_in);
+        if (h_out) (void) hipHostFree(h_out);
+        d_H = d_tw = nullptr; h_in = h_out = d_hin = d_hout = nullptr; stream = nullptr; device = -1; N = 0; rows = 0; in_floats = 0;
     }
     ~RawPlan() { release(); }
 };
 thread_local RawPlan g_raw;
 }
-
-extern "C" int irb_ir_to_real_fft_raw_engine_(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows);   // deconv_engine.hip
 
 int irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_size, float *out, int out_len, int *n_rows)
 {
@@ -1975,15 +2232,18 @@ int irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_siz
     const int N = ir_part_size * 2, M = ir_part_size;                 // :108
     if ((long) out_len < (long) bufcount * N) return fail(IRB_ERR_ARG, "out too small");
     const int np = (len + ir_part_size - 1) / ir_part_size;
-    if (env_int("IRB_RAW_DIRECT", 1) == 0) return irb_ir_to_real_fft_raw_engine_(device, ir, len, ir_part_size, out, out_len, n_rows);   // (A/B, tests)
     HIP_TRY(hipSetDevice(device));
     RawPlan &g = g_raw;
-    if (g.device != device || g.N != N || g.rows < (size_t) np) {
+    if (g.device != device || g.N != N || g.rows < (size_t) np || g.in_floats < (size_t) len) {
         g.release();
         hipError_t e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g.d_tw), sizeof(float2) * (size_t) N);
-        const size_t rows = ((size_t) np + 63) / 64 * 64;
+        const size_t rows = ((size_t) np + 63) / 64 * 64, in_floats = rows * (size_t) ir_part_size;
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&g.d_H), sizeof(float2) * rows * M);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g.h_in), sizeof(float) * in_floats, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g.h_out), sizeof(float2) * rows * M, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&g.d_hin), g.h_in, 0);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&g.d_hout), g.h_out, 0);
         std::vector<float2> tw((size_t) N);
         for (int j = 0; j < N; j++) {                                 // twiddles: W_N^j in double, rounded to float (as irb_fdl_create)
             const double ph = -2.0 * 3.14159265358979323846 * (double) j / (double) N;
@@ -1992,35 +2252,51 @@ int irb_ir_to_real_fft_raw(int device, const float *ir, int len, int ir_part_siz
         if (e == hipSuccess) e = hipMemcpy(g.d_tw, tw.data(), sizeof(float2) * (size_t) N, hipMemcpyHostToDevice);
         g.device = device;                                            // (so that release() frees whatever exists)
         if (e != hipSuccess) { g.release(); return fail(IRB_ERR_HIP, "IRtoRealFFTRaw plan: %s", hipGetErrorString(e)); }
-        g.N = N; g.rows = rows;
+        g.N = N; g.rows = rows; g.in_floats = in_floats;
     }
-    {
-        DeviceQuiet quiet(device);                                    // registration is a device-wide operation for the runtime
+    auto transform = [&](const float *d_src, float2 *d_dst) -> int {              // rows [0, np) of the IR at d_src -> d_dst
+        irb::IrDirectArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src[0] = a.src[1] = d_src;
+        a.H = d_dst; a.tw = g.d_tw; a.stream_info = nullptr; a.ninfo = 0;
+        a.average = 0; a.nrows = 1; a.len = len; a.B = ir_part_size; a.P = (int) g.rows; a.first_set = 0; a.np = np; a.np_pad = np;
+        FOR_N(N, irb::k_ir_fft_direct<NN><<<dim3((np + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, g.stream>>>(a));
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? IRB_OK : fail(IRB_ERR_HIP, "IRtoRealFFTRaw: %s", hipGetErrorString(e));
+    };
+    auto finish = [&]() {
+        if (bufcount > np) std::memset(out + (size_t) np * N, 0, sizeof(float) * (size_t) (bufcount - np) * N);   // an untouched last buffer stays zero
+        if (n_rows) *n_rows = bufcount;
+        return IRB_OK;
+    };
+    const DirectMode mode = direct_mode_from_env();
+    if (mode != DirectMode::kNever) {
+        std::unique_ptr<DeviceQuiet> quiet;
+        if (mode == DirectMode::kRegister) quiet.reset(new DeviceQuiet(device));   // registration is a device-wide operation for the runtime
         HostRanges ranges;
         const float *irp[1] = {ir};
         float *outp[1] = {out};
         ranges.add(irp, 1, (size_t) len);
         ranges.add(outp, 1, (size_t) np * N);
         const float *d_ir = nullptr;
-        if (ranges.commit() && (d_ir = ranges.dev(ir)) != nullptr) {
-            irb::IrDirectArgs a;
-            std::memset(&a, 0, sizeof a);
-            a.src[0] = a.src[1] = d_ir;
-            a.H = g.d_H; a.tw = g.d_tw; a.stream_info = nullptr; a.ninfo = 0;
-            a.average = 0; a.nrows = 1; a.len = len; a.B = ir_part_size; a.P = (int) g.rows; a.first_set = 0; a.np = np; a.np_pad = np;
-            FOR_N(N, irb::k_ir_fft_direct<NN><<<dim3((np + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, g.stream>>>(a));
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(out, g.d_H, sizeof(float) * (size_t) np * N, hipMemcpyDeviceToHost, g.stream);
+        float *d_out = nullptr;
+        if (ranges.commit(mode == DirectMode::kRegister) && (d_ir = ranges.dev(ir)) != nullptr && (d_out = ranges.dev(out)) != nullptr) {
+            const int rct = transform(d_ir, reinterpret_cast<float2 *>(d_out));
             const hipError_t es = hipStreamSynchronize(g.stream);     // also on failure: nothing may still touch the caller's memory
             ranges.release();
-            if (e != hipSuccess || es != hipSuccess) return fail(IRB_ERR_HIP, "IRtoRealFFTRaw: %s", hipGetErrorString(e != hipSuccess ? e : es));
-            if (bufcount > np) std::memset(out + (size_t) np * N, 0, sizeof(float) * (size_t) (bufcount - np) * N);   // an untouched last buffer stays zero
-            if (n_rows) *n_rows = bufcount;
-            return IRB_OK;
+            if (rct != IRB_OK) return rct;
+            if (es != hipSuccess) return fail(IRB_ERR_HIP, "IRtoRealFFTRaw: %s", hipGetErrorString(es));
+            return finish();
         }
         ranges.release();
     }
-    return irb_ir_to_real_fft_raw_engine_(device, ir, len, ir_part_size, out, out_len, n_rows);
+    std::memcpy(g.h_in, ir, sizeof(float) * (size_t) len);
+    const int rct = transform(g.d_hin, reinterpret_cast<float2 *>(g.d_hout));
+    const hipError_t es = hipStreamSynchronize(g.stream);
+    if (rct != IRB_OK) return rct;
+    if (es != hipSuccess) return fail(IRB_ERR_HIP, "IRtoRealFFTRaw: %s", hipGetErrorString(es));
+    std::memcpy(out, g.h_out, sizeof(float) * (size_t) np * N);
+    return finish();
 }
 
 void irb_fdl_release_cached_engine_(void)

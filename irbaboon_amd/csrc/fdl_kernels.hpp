@@ -87,6 +87,12 @@ struct StepArgs {
     // ... and the samples that exist behind `in` / may be written behind `out`, per stream (irb_convolve_periodic lets these kernels read
     // the caller's audio and write the caller's result buffer in place: blocks past the end read as zeros / are cut off)
     long          in_len, out_len;
+    // k_ifft_ola_run for the staged one-shot call: ONE launch writes all blocks of a piece into pinned host memory and tells the host
+    // chunk by chunk -- a wave that has written block j counts it in ck_cnt[j / ck_blocks] (device memory), the wave that completes a
+    // chunk stores ck_seq into the chunk's word in mapped host memory (ck_flag + 16 * chunk: one cache line each)
+    unsigned     *ck_cnt, *ck_flag;
+    int           ck_blocks;
+    unsigned      ck_seq;
 };
 
 #ifdef IRB_STAMPS

@@ -34,8 +34,8 @@
 // tests/kernel_model.py (mfma_time_axis) and checked against the direct sum on a machine without a GPU.
 // Non-finite input: 0 * X products exist for X blocks next to the ones an output really depends on (zero taps in front of
 // and behind the IR, up to 255 blocks later / 31 blocks earlier), so an Inf or NaN sample can spread further along the time
-// axis than in the reference; finite input is unaffected.  Xt is zeroed at create and only ever holds spectra, so the blocks
-// a tile reads beyond the end of a call are finite.
+// axis than in the reference WITHIN a call; finite input is unaffected.  Between calls nothing leaks: the only blocks beyond a call's
+// last one that its kept outputs touch are the rest of the last segment of 16, and k_push_fft_batch_t writes those as zeros.
 #pragma once
 
 #ifndef IRB_MFMA_EXP
@@ -162,8 +162,10 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     }
     __syncthreads();
     // Xt[s][bin][xt_hist + j0 .. + NBW), inside every segment of 16 blocks in mfma_xt_float order: thread -> (bin, slot p of the
-    // workgroup's blocks); consecutive threads write consecutive slots (whole 128-byte lines for NBW = 16).  Blocks beyond the
-    // call's last one are not written (their waves transformed nothing).
+    // workgroup's blocks); consecutive threads write consecutive slots (whole 128-byte lines for NBW = 16).  The blocks between the
+    // call's last one and the end of ITS segment of 16 are written as zeros: k_cmac_mfma multiplies them (by zero taps) into the last
+    // outputs of the call, and what an earlier, longer call left there may be non-finite (0 * NaN; a cached one-shot engine, a
+    // streaming handle after a burst -- the reference's calls are independent).
     float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist;
     const int t_end = a.t_first + a.t_count;
     for (int e = threadIdx.x; e < M * NBW; e += kWave * NBW) {
@@ -171,13 +173,24 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: slot p takes one component of two of its blocks
             const int c = (p >> 1) & 1, t = mfma_xt_slot_block(p);
             float2 *dst = xt + (size_t) bin * a.xt_len + j0 + p;
-            if (j0 + t + 4 < t_end) nt_store2(dst, make_float2(mfma_component(l_buf[t][bin], c), mfma_component(l_buf[t + 4][bin], c)));
-            else if (j0 + t < t_end) reinterpret_cast<float *>(dst)[0] = mfma_component(l_buf[t][bin], c);
+            nt_store2(dst, make_float2(j0 + t < t_end ? mfma_component(l_buf[t][bin], c) : 0.f, j0 + t + 4 < t_end ? mfma_component(l_buf[t + 4][bin], c) : 0.f));
         } else {                                       // part of a segment: the two components of block j0 + p go to their (scattered) floats
-            if (j0 + p < t_end) {
+            float *xf = reinterpret_cast<float *>(xt + (size_t) bin * a.xt_len);
+            const bool have = j0 + p < t_end;
+            xf[mfma_xt_float(j0 + p, 0)] = have ? l_buf[p][bin].x : 0.f;
+            xf[mfma_xt_float(j0 + p, 1)] = have ? l_buf[p][bin].y : 0.f;
+        }
+    }
+    if constexpr (NBW < kMfmaSeg) {
+        // (the workgroup that holds the call's last block also clears the blocks of that segment behind its own)
+        const int seg_end = (t_end + kMfmaSeg - 1) / kMfmaSeg * kMfmaSeg;
+        if (j0 < t_end && j0 + NBW >= t_end && j0 + NBW < seg_end) {
+            const int extra = seg_end - (j0 + NBW);
+            for (int e = threadIdx.x; e < M * extra; e += kWave * NBW) {
+                const int bin = e / extra, t = j0 + NBW + e % extra;
                 float *xf = reinterpret_cast<float *>(xt + (size_t) bin * a.xt_len);
-                xf[mfma_xt_float(j0 + p, 0)] = l_buf[p][bin].x;
-                xf[mfma_xt_float(j0 + p, 1)] = l_buf[p][bin].y;
+                xf[mfma_xt_float(t, 0)] = 0.f;
+                xf[mfma_xt_float(t, 1)] = 0.f;
             }
         }
     }

@@ -375,12 +375,35 @@ __global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, i
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
             const int n = lane + i * kWave;
-            if (n < a.B && n < room) out[n] = y[n] * scale + yp[a.B + n] * scale;
+            if (n < a.B && n < room) {
+                const float v = y[n] * scale + yp[a.B + n] * scale;
+                // (staged one-shot call: written THROUGH to the host's staging -- an ordinary store may stay in the L2 until the
+                // kernel ends, long after the chunk's word below has told the host to read)
+                if (a.ck_flag) __hip_atomic_store(out + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else out[n] = v;
+            }
         }
     }
     if (j == a.T - 1) {
         float *on = a.ovl_next + (size_t) s * a.B;
         for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
+    }
+    if (a.ck_flag && wave >= 1) {
+        // staged one-shot call: block j of stream s has left for the host's staging.  Its samples were stored write-through (system
+        // scope), so "left" = acknowledged = vmcnt(0); a release FENCE here would write the whole L2 back, per wave (measured: this
+        // kernel 173 us instead of 86).  Then the count (relaxed: ordering comes from the wait in
+        // front of it and from the data dependence on its result); the count's last arriver clears it for the next piece and
+        // raises the chunk's word -- issued after every other wave's samples were acknowledged, so behind them on the link.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int ck = j / a.ck_blocks;
+            const unsigned expect = (unsigned) S * (unsigned) min(a.ck_blocks, a.T - ck * a.ck_blocks);
+            const unsigned old = __hip_atomic_fetch_add(a.ck_cnt + ck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == expect) {
+                __hip_atomic_store(a.ck_cnt + ck, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ck_flag + 16 * ck, a.ck_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 

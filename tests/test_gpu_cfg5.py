@@ -237,10 +237,10 @@ def test_convolve_nonperiodic_long():
 
 
 def test_convolve_nonperiodic_direct_and_staged_forms_agree(monkeypatch):
-    """irb_convolve_nonperiodic moves the samples straight between the caller's (registered) buffers and the device; the staged form
-    (IRB_NONPERIODIC_DIRECT=0: host vectors, pageable copies) is what serves the stereo-IR-to-mono layout and refused registrations.
-    Same kernels either way: identical bits, a poisoned result buffer fully overwritten, for the layouts the direct form takes,
-    ragged lengths, audio and IR in one allocation."""
+    """irb_convolve_nonperiodic stages pageable buffers through the plan's pinned memory (the default, and what serves the
+    stereo-IR-to-mono layout); with IRB_OFFLINE_DIRECT=1 the copy engine moves the samples straight between the caller's registered
+    buffers and the device.  Same kernels either way: identical bits, a poisoned result buffer fully overwritten, ragged lengths,
+    audio and IR in one allocation."""
     from irbaboon_amd import _lib
     lib = _lib.lib()
     fpp = lambda arrs: (_lib.fp * len(arrs))(*[a.ctypes.data_as(_lib.fp) for a in arrs])
@@ -254,8 +254,11 @@ def test_convolve_nonperiodic_direct_and_staged_forms_agree(monkeypatch):
         for c in range(Ci):
             hs[c][:] = decaying_ir(8650 + 10 * k + c, Lh)
         outs = []
-        for direct in ("1", "0"):
-            monkeypatch.setenv("IRB_NONPERIODIC_DIRECT", direct)
+        for direct in ("1", None):
+            if direct:
+                monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+            else:
+                monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
             out = [np.full(La + Lh - 1, 1e30, np.float32) for _ in range(Ca)]
             _lib.check(lib.irb_convolve_nonperiodic(0, fpp(xs), Ca, La, fpp(hs), Ci, Lh, fpp(out)))
             outs.append(np.stack(out))
@@ -266,17 +269,26 @@ def test_convolve_nonperiodic_direct_and_staged_forms_agree(monkeypatch):
     lib.irb_release_cached_plans()
 
 
-def test_ir_to_real_fft_raw_light_path_equals_the_engine_path(monkeypatch):
-    """irb_ir_to_real_fft_raw transforms the caller's IR where it lies (registered for the call, one launch, one copy back, a small
-    per-thread device buffer) instead of building an engine per call; IRB_RAW_DIRECT=0 is the old path, kept for buffers the runtime
-    refuses to register.  Identical bits, for partition sizes 16 ... 2048, ragged and exact lengths, growing and shrinking IRs."""
+def test_ir_to_real_fft_raw_forms_agree_with_an_engine(monkeypatch):
+    """irb_ir_to_real_fft_raw: one launch transforms the IR in the per-thread pinned staging (default) or where it lies in the caller's
+    registered pages (IRB_OFFLINE_DIRECT=1), rows written straight to where the host reads them.  Both identical to the rows an FDL
+    engine holds for the same IR (irb_fdl_get_ir_spectra), for partition sizes 16 ... 2048, ragged and exact lengths, growing and
+    shrinking IRs."""
     for n, ps in [(700, 64), (96000, 256), (5, 16), (2048 * 3, 2048), (1000, 512), (96000, 512), (300, 256)]:
         h = decaying_ir(9000 + n, n)
         outs = []
-        for direct in ("1", "0"):
-            monkeypatch.setenv("IRB_RAW_DIRECT", direct)
+        for direct in ("1", None):
+            if direct:
+                monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+            else:
+                monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
             outs.append(ib.IRtoRealFFTRaw(h, ps))
         assert outs[0].shape == (n // ps + 1, 2 * ps) and np.array_equal(outs[0], outs[1])
+        npart = (n + ps - 1) // ps
+        with ib.FdlEngine(1, 1, ps, n) as eng:
+            eng.set_ir(0, h[None])
+            rows = eng.get_ir_spectra(0, 0, npart)
+        assert np.array_equal(rows, outs[0][:npart])
     from irbaboon_amd import _lib
     _lib.lib().irb_release_cached_plans()
 

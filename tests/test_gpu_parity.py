@@ -123,21 +123,43 @@ def test_convolve_periodic_edge_cases():
     assert rel_rms(y, direct_f64(x, h)) < RMS_TOL
 
 
-@pytest.mark.parametrize("direct", ["1", "0"], ids=["direct", "staged"])
-def test_convolve_periodic_in_several_pieces(monkeypatch, direct):
+def _dbg(monkeypatch, **kv):
+    """the library's internal knobs: ONE variable, IRB_DEBUG="name=value,..." (tests and tools only)"""
+    if kv:
+        monkeypatch.setenv("IRB_DEBUG", ",".join(f"{k}={v}" for k, v in kv.items()))
+    else:
+        monkeypatch.delenv("IRB_DEBUG", raising=False)
+
+
+def _form(monkeypatch, form):
+    """'staged' = the default for pageable buffers; 'registered' = the opt-in form (IRB_OFFLINE_DIRECT=1)"""
+    if form == "registered":
+        monkeypatch.setenv("IRB_OFFLINE_DIRECT", "1")
+    else:
+        monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
+
+
+def _last_profile():
+    prof = _lib.ConvolveProfile()
+    _lib.check(_lib.lib().irb_convolve_last_profile(ctypes.byref(prof)))
+    return prof
+
+
+@pytest.mark.parametrize("form", ["staged", "registered"])
+def test_convolve_periodic_in_several_pieces(monkeypatch, form):
     """irb_convolve_periodic on signals longer than one multiply takes: the FDL (ring, overlap, the matrix-core path's history
-    columns) carries from piece to piece.  25 062 steps at B = 16 are two pieces of the default 16 384; IRB_OFFLINE_MAX_BLOCKS = 700 /
-    5 makes it many (on the matrix cores / on the packed-FMA tile).  Both forms of the call: the kernels working in the caller's
-    registered memory, and pinned staging."""
-    monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+    columns) carries from piece to piece.  25 062 steps at B = 16 are two pieces of the default 16 384; offline_max_blocks = 700 /
+    5 makes it many (on the matrix cores / on the packed-FMA tile).  Both forms of the call: pinned staging (the default for
+    pageable buffers) and the kernels working in the caller's registered memory (opt-in)."""
+    _form(monkeypatch, form)
     B, Lh, La = 16, 1000, 400000
     x, h = white_noise(7700, La)[None], decaying_ir(7701, Lh)[None]
     ref = scipy.signal.fftconvolve(x[0].astype(np.float64), h[0].astype(np.float64))
-    for max_blocks in (None, "700", "5"):
-        if max_blocks:
-            monkeypatch.setenv("IRB_OFFLINE_MAX_BLOCKS", max_blocks)
-        n = La if max_blocks != "5" else 2000                       # (five-block pieces: a short signal is enough)
+    for max_blocks in (None, 700, 5):
+        _dbg(monkeypatch, **({"offline_max_blocks": max_blocks} if max_blocks else {}))
+        n = La if max_blocks != 5 else 2000                         # (five-block pieces: a short signal is enough)
         y = convolvePeriodic(x[:, :n], h, B, keep_reference_tail=False)
+        assert _last_profile().direct == (1 if form == "registered" else 0)
         r = ref if n == La else scipy.signal.fftconvolve(x[0, :n].astype(np.float64), h[0].astype(np.float64))
         assert y.shape == (1, n + Lh - 1) and rel_rms(y[0], r) < RMS_TOL
         irbaboon_amd_release()
@@ -148,11 +170,95 @@ def irbaboon_amd_release():
     irbaboon_amd.lib().irb_release_cached_plans()
 
 
-def test_convolve_periodic_on_awkward_caller_memory():
-    """The direct form registers the caller's pages: channels in separate allocations, pointers that are not even 16-byte aligned,
-    audio and result living in ONE allocation (shared pages: one registration), and a result buffer that is pinned memory already
-    (registration refused: the staged form takes over) -- all through the C ABI with hand-made pointer arrays."""
-    import ctypes
+def test_one_shot_calls_never_register_pageable_memory_by_default(monkeypatch):
+    """Round 5 rule: the zero-copy form of irb_convolve_periodic is taken only for buffers that are HIP host memory
+    already.  numpy arrays (pageable) -> staged, nothing registered; irb_host_alloc buffers -> direct, still nothing registered;
+    pinned audio with a pageable result -> staged.  All against the oracle, and the two forms bit-identical (same kernels, same
+    samples).  irb_convolve_nonperiodic and irb_ir_to_real_fft_raw follow the same rule (no profile there: parity of both)."""
+    from irbaboon_amd.engine import pinned_empty
+    from irbaboon_amd import convolveNonPeriodic, IRtoRealFFTRaw
+    monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
+    lib = _lib.lib()
+    for B, Ca, Ci, La, Lh in ((256, 2, 2, 35656, 6168), (128, 1, 1, 300000, 20000), (64, 1, 2, 5000, 700)):
+        x = np.stack([white_noise(8800 + c, La) for c in range(Ca)])
+        h = np.stack([decaying_ir(8810 + c, Lh) for c in range(Ci)])
+        ref, _ = oracle.convolve_periodic(x, h, B)
+        y = convolvePeriodic(x, h, B)                                     # pageable everything
+        p = _last_profile()
+        assert (p.direct, p.registered_ranges) == (0, 0)
+        px, ph, py = pinned_empty(x.shape), pinned_empty(h.shape), pinned_empty(y.shape)
+        px[:], ph[:] = x, h
+        py[:] = np.float32(1e30)
+        _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(px), Ca, La, _lib.planar_ptrs(ph), Ci, Lh, B, 1, _lib.planar_ptrs(py)))
+        p = _last_profile()
+        assert (p.direct, p.registered_ranges) == (1, 0)
+        assert np.array_equal(np.asarray(py), y)
+        for c in range(Ca):
+            assert rel_rms(y[c], ref[c]) < RMS_TOL
+        # pinned audio and IR, pageable result: the result decides -- staged
+        out = np.full(y.shape, np.float32(1e30), np.float32)
+        _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(px), Ca, La, _lib.planar_ptrs(ph), Ci, Lh, B, 1, _lib.planar_ptrs(out)))
+        assert _last_profile().direct == 0 and np.array_equal(out, y)
+        # pageable audio, pinned IR and result: staged as well
+        py[:] = np.float32(1e30)
+        _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(x), Ca, La, _lib.planar_ptrs(ph), Ci, Lh, B, 1, _lib.planar_ptrs(py)))
+        assert _last_profile().direct == 0 and np.array_equal(np.asarray(py), y)
+        # the single-FFT function and the IR-spectra export: pageable and pinned buffers give the same samples
+        if Ci <= Ca:
+            ynp = convolveNonPeriodic(x, h)
+            pyn = pinned_empty(ynp.shape)
+            _lib.check(lib.irb_convolve_nonperiodic(0, _lib.planar_ptrs(px), Ca, La, _lib.planar_ptrs(ph), Ci, Lh, _lib.planar_ptrs(pyn)))
+            assert np.array_equal(np.asarray(pyn), ynp)
+            for c in range(Ca):
+                full = scipy.signal.fftconvolve(x[c].astype(np.float64), h[c if Ci == Ca else 0].astype(np.float64))
+                assert rel_rms(ynp[c], full) < RMS_TOL
+        rows = IRtoRealFFTRaw(h[0], 256)
+        prow = pinned_empty(rows.shape)
+        prow[:] = np.float32(1e30)
+        _lib.check(lib.irb_ir_to_real_fft_raw(0, ph[0].ctypes.data_as(_lib.fp), Lh, 256, prow.ctypes.data_as(_lib.fp), prow.size, ctypes.byref(ctypes.c_int(0))))
+        assert np.array_equal(np.asarray(prow), rows)
+    lib.irb_release_cached_plans()
+
+
+def test_staged_pipeline_threads_and_chunking(monkeypatch):
+    """The staged form's host pipeline: any number of threads (the caller alone, the default three, more), helpers forced onto
+    calls too short to want them, chunks of 16 blocks (hundreds of chunk words per piece, and more chunks than there are words:
+    the chunk size doubles) -- every variant bit-identical to the one-thread call and equal to the oracle; ragged ends, both tail
+    modes, stereo."""
+    monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
+    for B, Ca, Ci, La, Lh in ((256, 2, 2, 256 * 700 + 77, 256 * 20 + 3), (16, 1, 1, 16 * 20000 + 5, 16 * 30), (128, 2, 1, 50001, 1000)):
+        x = np.stack([white_noise(8900 + c, La) for c in range(Ca)])
+        h = np.stack([decaying_ir(8910 + c, Lh) for c in range(Ci)])
+        ref, _ = oracle.convolve_periodic(x, h, B)
+        for keep in (True, False):
+            monkeypatch.setenv("IRB_OFFLINE_THREADS", "1")
+            _dbg(monkeypatch)
+            y1 = convolvePeriodic(x, h, B, keep_reference_tail=keep)
+            assert _last_profile().threads == 1
+            nwk = min(La + Lh - 1, (La // B + -(-Lh // B)) * B)
+            for c in range(Ca):
+                assert rel_rms(y1[c, :nwk], ref[c, :nwk]) < RMS_TOL
+            for threads, dbg in (("3", {}), ("3", {"offline_helpers_from": 0}), ("5", {"offline_helpers_from": 0, "offline_chunk": 16}),
+                                 ("2", {"offline_helpers_from": 0, "offline_chunk": 16, "offline_max_blocks": 300})):
+                monkeypatch.setenv("IRB_OFFLINE_THREADS", threads)
+                _dbg(monkeypatch, **dbg)
+                y = convolvePeriodic(x, h, B, keep_reference_tail=keep)
+                p = _last_profile()
+                assert p.direct == 0 and (p.threads == int(threads) or "offline_helpers_from" not in dbg)
+                if "offline_max_blocks" not in dbg:
+                    assert np.array_equal(y, y1), (B, threads, dbg)
+                else:                                              # (another split into pieces: another summation order inside the multiply)
+                    for c in range(Ca):
+                        assert rel_rms(y[c, :nwk], ref[c, :nwk]) < RMS_TOL
+                irbaboon_amd_release()
+    monkeypatch.delenv("IRB_OFFLINE_THREADS")
+
+
+def test_convolve_periodic_on_awkward_caller_memory(monkeypatch):
+    """The opt-in direct form (IRB_OFFLINE_DIRECT=1) registers the caller's pages: channels in separate allocations, pointers that
+    are not even 16-byte aligned, audio and result living in ONE allocation (shared pages: one registration), and a result buffer
+    that is pinned memory already (used as it is, only the audio is registered) -- all through the C ABI with hand-made pointer
+    arrays.  The same awkward layouts through the default staged form give the same samples."""
     lib = _lib.lib()
     B, Lh, La = 256, 5000, 60000
     h = np.stack([decaying_ir(7800, Lh), decaying_ir(7801, Lh)])
@@ -165,10 +271,10 @@ def test_convolve_periodic_on_awkward_caller_memory():
     audio = [big[a_off[c]:a_off[c] + La] for c in range(2)]
     out = [big[o_off[c]:o_off[c] + La + Lh - 1] for c in range(2)]
     hp = _lib.planar_ptrs(h)
-    prof = _lib.ConvolveProfile()
+    _form(monkeypatch, "registered")
     _lib.check(lib.irb_convolve_periodic(0, fpp(audio), 2, La, hp, 2, Lh, B, 0, fpp(out)))
-    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
-    assert prof.direct == 1
+    p = _last_profile()
+    assert p.direct == 1 and p.registered_ranges >= 1
     for c in range(2):
         assert rel_rms(out[c], scipy.signal.fftconvolve(xs[c].astype(np.float64), h[c].astype(np.float64))) < RMS_TOL
         assert np.array_equal(big[a_off[c]:a_off[c] + La], xs[c])    # the audio next to it is untouched
@@ -177,29 +283,36 @@ def test_convolve_periodic_on_awkward_caller_memory():
     _lib.check(lib.irb_convolve_periodic(0, fpp(xs), 2, La, hp, 2, Lh, B, 0, fpp(sep_out)))
     for c in range(2):
         assert rel_rms(sep_out[c], out[c]) < 2e-6
-    # a result buffer the caller pinned itself: the runtime refuses to register it again
+    # a result buffer the caller pinned itself
     from irbaboon_amd.engine import pinned_empty
     pin = pinned_empty((2, La + Lh - 1))
     _lib.check(lib.irb_convolve_periodic(0, fpp(xs), 2, La, hp, 2, Lh, B, 0, _lib.planar_ptrs(pin)))
-    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
+    assert _last_profile().direct == 1
     assert rel_rms(pin, np.stack(out)) < 2e-6
+    # the default form on the one-allocation layout: staged, same samples, neighbours untouched
+    _form(monkeypatch, "staged")
+    want = [o.copy() for o in out]
+    for o in out:
+        o[:] = np.float32(1e30)
+    _lib.check(lib.irb_convolve_periodic(0, fpp(audio), 2, La, hp, 2, Lh, B, 0, fpp(out)))
+    assert _last_profile().direct == 0
+    for c in range(2):
+        assert np.array_equal(out[c], want[c])
+        assert np.array_equal(big[a_off[c]:a_off[c] + La], xs[c])
     lib.irb_release_cached_plans()
 
 
-@pytest.mark.parametrize("direct", ["1", "0"], ids=["direct", "staged"])
-def test_convolve_periodic_writes_every_sample_of_the_result(monkeypatch, direct):
+@pytest.mark.parametrize("form", ["staged", "registered"])
+def test_convolve_periodic_writes_every_sample_of_the_result(monkeypatch, form):
     """The Python mirror hands the library an UNINITIALISED result array (np.empty): every sample the call produces must be
     written by it and the reference's dropped tail must be zeroed by it (fp/convolution.cpp:225-227,236-238).  Result buffers
     poisoned beforehand, ragged and block-aligned lengths, both tail modes, one and several pieces, both forms."""
     lib = _lib.lib()
-    monkeypatch.setenv("IRB_OFFLINE_DIRECT", direct)
+    _form(monkeypatch, form)
     poison = np.float32(1e30)
     for k, (B, Ca, Ci, La, Lh, pieces) in enumerate([(256, 2, 2, 35656, 6168, 0), (64, 1, 2, 64 * 40, 64 * 3, 0), (128, 2, 1, 5001, 1, 0), (32, 1, 1, 7, 900, 0),
                                                      (100, 2, 2, 12345, 777, 40), (16, 1, 1, 16 * 300 + 5, 16 * 20, 5)]):
-        if pieces:
-            monkeypatch.setenv("IRB_OFFLINE_MAX_BLOCKS", str(pieces))
-        else:
-            monkeypatch.delenv("IRB_OFFLINE_MAX_BLOCKS", raising=False)
+        _dbg(monkeypatch, **({"offline_max_blocks": pieces, "offline_helpers_from": 0} if pieces else {"offline_helpers_from": 0}))
         x = np.stack([white_noise(7900 + 10 * k + c, La) for c in range(Ca)])
         h = np.stack([decaying_ir(7950 + 10 * k + c, Lh) for c in range(Ci)])
         for keep in (1, 0):
@@ -218,25 +331,23 @@ def test_convolve_periodic_writes_every_sample_of_the_result(monkeypatch, direct
         lib.irb_release_cached_plans()
 
 
-def test_convolve_periodic_reads_the_impulse_response_where_it_lies(tmp_path, monkeypatch):
-    """The direct form transforms the caller's impulse response in place (k_ir_fft_direct: no staging copy): all four channel layouts
-    incl. the stereo IR averaged for mono audio (tools::sumToMono, fp/tools.cpp:25-28), ragged IR lengths, an IR in the SAME
-    allocation as the audio (one registration) -- each against the oracle and bit-identical to the staged IR set-up
-    (IRB_OFFLINE_IR_DIRECT=0).  An IR in a read-only file mapping is refused by the runtime's registration: the call then
-    falls back (audio still direct) and gives the same samples."""
-    import ctypes
+def test_convolve_periodic_impulse_response_set_up(tmp_path, monkeypatch):
+    """The IR's set-up is one launch that transforms the samples where they lie (k_ir_fft_direct): in the engine's pinned IR staging
+    (default form) or in the caller's own registered pages (opt-in form) -- all four channel layouts incl. the stereo IR averaged
+    for mono audio (tools::sumToMono, fp/tools.cpp:25-28), ragged IR lengths, an IR in the SAME allocation as the audio, each
+    against the oracle and the two forms bit-identical.  An IR in a read-only file mapping: the opt-in form's registration of it is
+    refused (audio still direct), the default form just copies it -- the same samples."""
     lib = _lib.lib()
     B = 128
-    prof = _lib.ConvolveProfile()
     for Ca, Ci, La, Lh in ((1, 1, 40000, 3001), (2, 2, 33000, 128 * 7), (2, 1, 12345, 999), (1, 2, 20000, 5000)):
         x = np.stack([white_noise(8300 + c, La) for c in range(Ca)])
         h = np.stack([decaying_ir(8310 + c, Lh) for c in range(Ci)])
         ref, _ = oracle.convolve_periodic(x, h, B)
         outs = []
-        for direct in ("1", "0"):
-            monkeypatch.setenv("IRB_OFFLINE_IR_DIRECT", direct)
+        for form in ("registered", "staged"):
+            _form(monkeypatch, form)
             outs.append(convolvePeriodic(x, h, B))
-        monkeypatch.delenv("IRB_OFFLINE_IR_DIRECT")
+            assert _last_profile().direct == (1 if form == "registered" else 0)
         assert np.array_equal(outs[0], outs[1])
         for c in range(Ca):
             assert rel_rms(outs[0][c], ref[c]) < RMS_TOL
@@ -246,22 +357,44 @@ def test_convolve_periodic_reads_the_impulse_response_where_it_lies(tmp_path, mo
     big[0, 5:5 + La] = white_noise(8350, La)
     big[0, 5 + La + 3:5 + La + 3 + Lh] = decaying_ir(8351, Lh)
     xa, ha = big[:, 5:5 + La], big[:, 5 + La + 3:5 + La + 3 + Lh]
-    out = np.empty((1, La + Lh - 1), np.float32)
     fpp = lambda arrs: (_lib.fp * len(arrs))(*[a.ctypes.data_as(_lib.fp) for a in arrs])
-    _lib.check(lib.irb_convolve_periodic(0, fpp([xa[0]]), 1, La, fpp([ha[0]]), 1, Lh, B, 1, fpp([out[0]])))
     ref, _ = oracle.convolve_periodic(np.ascontiguousarray(xa), np.ascontiguousarray(ha), B)
-    assert rel_rms(out[0], ref[0]) < RMS_TOL
+    for form in ("registered", "staged"):
+        _form(monkeypatch, form)
+        out = np.empty((1, La + Lh - 1), np.float32)
+        _lib.check(lib.irb_convolve_periodic(0, fpp([xa[0]]), 1, La, fpp([ha[0]]), 1, Lh, B, 1, fpp([out[0]])))
+        assert rel_rms(out[0], ref[0]) < RMS_TOL
     # an IR the process may only read
     path = tmp_path / "ir.f32"
     decaying_ir(8360, 4096).tofile(path)
     hm = np.memmap(path, dtype=np.float32, mode="r")
     x = white_noise(8361, 50000)[None]
-    y = np.empty((1, 50000 + 4096 - 1), np.float32)
-    _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(x), 1, 50000, fpp([hm]), 1, 4096, B, 1, _lib.planar_ptrs(y)))
-    _lib.check(lib.irb_convolve_last_profile(ctypes.byref(prof)))
     ref, _ = oracle.convolve_periodic(x, np.array(hm)[None], B)
-    assert rel_rms(y[0], ref[0]) < RMS_TOL
+    for form in ("registered", "staged"):
+        _form(monkeypatch, form)
+        y = np.empty((1, 50000 + 4096 - 1), np.float32)
+        _lib.check(lib.irb_convolve_periodic(0, _lib.planar_ptrs(x), 1, 50000, fpp([hm]), 1, 4096, B, 1, _lib.planar_ptrs(y)))
+        assert rel_rms(y[0], ref[0]) < RMS_TOL
     lib.irb_release_cached_plans()
+
+
+def test_nothing_non_finite_leaks_from_one_call_into_the_next():
+    """the matrix-core path keeps the FDL a second time with time contiguous per bin (Xt); the blocks between a call's last
+    one and the end of its segment of 16 are multiplied into the call's last outputs by ZERO taps -- so whatever an earlier, longer
+    call on the same cached engine left there must not be NaN or Inf.  A call with an Inf sample, then a shorter finite call whose
+    last segment ends over the Inf's block: the second result is finite and equals the oracle (the reference's calls are independent,
+    fp/convolution.cpp:14-242 keeps no state)."""
+    B, Lh = 16, 16 * 10
+    h = decaying_ir(9001, Lh)[None]
+    x1 = white_noise(9002, 16 * 400)[None].copy()
+    x1[0, 16 * 300 + 3] = np.inf
+    y1 = convolvePeriodic(x1, h, B)
+    assert not np.isfinite(y1).all()
+    x2 = white_noise(9003, 16 * 280)[None]                             # 280 + 10 = 290 steps: the last segment is blocks 288 .. 303
+    y2 = convolvePeriodic(x2, h, B)
+    ref, _ = oracle.convolve_periodic(x2, h, B)
+    assert np.isfinite(y2).all() and rel_rms(y2[0], ref[0]) < RMS_TOL
+    irbaboon_amd_release()
 
 
 def test_delta_ir_is_pure_delay():

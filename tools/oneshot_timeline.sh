@@ -5,7 +5,7 @@ cfg=${1:-cfg1}
 R=/root/repo
 O=$R/gpurun_out/oneshot_tl_$cfg
 rm -rf $O; mkdir -p $O
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/tools/oneshot_probe.py $cfg 5 > $O/run.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/tools/oneshot_probe.py $cfg 5 $2 > $O/run.log 2>&1)
 python3 - $O $cfg <<'PY'
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"))[0]
