@@ -290,14 +290,31 @@ def nonperiodic_one_shot(dev, np, decaying_ir, white_noise, La=960000, Lh=96000,
         if rc != 0:
             raise SystemExit("irb_convolve_nonperiodic failed: " + lib.irb_last_error().decode())
     ms = float(np.median(tb)) * 1e3
+    # the same call with every buffer in irb_host_alloc memory: the copy engine moves the samples straight between them and the device
+    from irbaboon_amd.engine import pinned_empty
+    px, ph, pout = pinned_empty(x.shape), pinned_empty(h.shape), pinned_empty(out.shape)
+    px[:], ph[:] = x, h
+    pxp, php, pop = planar_ptrs(px), planar_ptrs(ph), planar_ptrs(pout)
+    tp = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        rc = lib.irb_convolve_nonperiodic(dev, pxp, 1, La, php, 1, Lh, pop)
+        tp.append(time.perf_counter() - t0)
+        if rc != 0:
+            raise SystemExit("irb_convolve_nonperiodic failed: " + lib.irb_last_error().decode())
+    if not np.array_equal(np.asarray(pout), out):
+        raise SystemExit("irb_convolve_nonperiodic: pinned and pageable buffers gave different samples")
     n = 1
     while n < La + Lh - 1:
         n *= 2
-    ent = {"wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(min(tb) * 1e3, 4),
+    ent = {"form": "staged (default for pageable buffers)",
+           "wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(min(tb) * 1e3, 4),
            "fft_len": n, "samples": La, "Msamples_per_s": round(La / ms / 1e3, 1), "calls_timed": reps,
            "pcie_GBps_both_ways": round(4 * (La + Lh + La + Lh - 1) / ms / 1e6, 2),
-           "note": "irb_convolve_nonperiodic, mono, 20 s of audio through a 2 s IR as one 2^21-point transform per signal; pageable numpy buffers, "
-                   "wall clock, plan cached from the first call; parity: tests/test_gpu_cfg5.py and the goldens"}
+           "direct_pinned": {"wall_ms_c_abi": round(float(np.median(tp[1:])) * 1e3, 4), "wall_ms_c_abi_min": round(min(tp[1:]) * 1e3, 4),
+                             "note": "audio, IR and result in irb_host_alloc memory (no host copy, nothing registered); same samples (checked here)"},
+           "note": "irb_convolve_nonperiodic, mono, 20 s of audio through a 2 s IR as one 2^21-point transform per signal; pageable numpy buffers through "
+                   "the plan's pinned staging, wall clock, plan cached from the first call; parity: tests/test_gpu_cfg5.py and the goldens"}
     lib.irb_release_cached_plans()
     return ent
 
@@ -314,7 +331,7 @@ def ir_spectra_raw(dev, np, decaying_ir, Lh=96000, ps=256, reps=25):
         IRtoRealFFTRaw(h, ps, device=dev)
         ts.append(time.perf_counter() - t0)
     return {"wall_ms_python_mirror": round(float(np.median(ts)) * 1e3, 4), "rows": int(raw.shape[0]), "floats_per_row": int(raw.shape[1]),
-            "note": "irb_ir_to_real_fft_raw: the IR transformed where it lies (registered for the call), one launch + one copy back; parity: tests/test_gpu_cfg5.py"}
+            "note": "irb_ir_to_real_fft_raw, pageable buffers (default form): one copy into pinned staging, one launch that writes the rows into pinned memory, one copy out; parity: tests/test_gpu_cfg5.py"}
 
 
 def cpu_nonperiodic(np, ent, La=960000, Lh=96000, reps=3):
@@ -335,49 +352,75 @@ def cpu_nonperiodic(np, ent, La=960000, Lh=96000, reps=3):
 
 def one_shot(dev, np, decaying_ir, white_noise, Ca, Ci, Bk, Lh, La, note, reps=21):
     """fp::convolution::convolvePeriodic (fp/convolution.hpp:31) as a maintainer binds it: irb_convolve_periodic, whole signal in, whole
-    signal out, PAGEABLE host buffers, wall clock.  Two figures: the Python mirror convolvePeriodic(...) (a fresh result array per call,
-    as a caller of the reference's function gets a fresh AudioBuffer) and the C ABI itself with the caller's buffers reused; plus the
-    library's own breakdown of the median-like call (irb_convolve_last_profile: host phases and hipEvent intervals)."""
+    signal out, wall clock.  The headline figures are the DEFAULT form for PAGEABLE host buffers (numpy arrays: the library's pinned
+    staging, nothing of the caller's registered): the Python mirror convolvePeriodic(...) (a fresh result array per call, as a caller
+    of the reference's function gets a fresh AudioBuffer) and the C ABI itself with the caller's buffers reused, plus the library's
+    own breakdown (irb_convolve_last_profile).  `direct_pinned`: the same call with audio, IR and result in irb_host_alloc memory
+    (the kernels work in the caller's buffers, no host copy, still nothing registered)."""
     import ctypes as C
     from irbaboon_amd import _lib, convolvePeriodic
     from irbaboon_amd._lib import planar_ptrs
+    from irbaboon_amd.engine import pinned_empty
+    if os.environ.get("IRB_OFFLINE_DIRECT") not in (None, "", "auto"):
+        raise SystemExit("bench.py measures the default one-shot forms: unset IRB_OFFLINE_DIRECT")
     x = np.stack([white_noise(4000 + c, La) for c in range(Ca)])
     h = np.stack([decaying_ir(4100 + c, Lh) for c in range(Ci)])
     lib = _lib.lib()
     lib.irb_convolve_profile_events(0)
     convolvePeriodic(x, h, Bk, device=dev)                           # builds the calling thread's engine
-    ta, tb, profs = [], [], []
+    ta = []
     for _ in range(reps):
         t0 = time.perf_counter()
         convolvePeriodic(x, h, Bk, device=dev)
         ta.append(time.perf_counter() - t0)
-    out = np.zeros((Ca, La + Lh - 1), np.float32)
-    xp, hp, op = planar_ptrs(x), planar_ptrs(h), planar_ptrs(out)
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        rc = lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
-        tb.append(time.perf_counter() - t0)
-        if rc != 0:
-            raise SystemExit("irb_convolve_periodic failed: " + lib.irb_last_error().decode())
-    lib.irb_convolve_profile_events(1)                               # a few more calls with the device-event part of the profile on
-    for _ in range(7):
+
+    def c_abi(xa, ha, outa):
+        xp, hp, op = planar_ptrs(xa), planar_ptrs(ha), planar_ptrs(outa)
+        tb, profs = [], []
         lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
-        p = _lib.ConvolveProfile()
-        lib.irb_convolve_last_profile(C.byref(p))
-        profs.append(p.as_dict())
-    lib.irb_convolve_profile_events(0)
-    med = {k: (round(float(np.median([p[k] for p in profs])), 4) if isinstance(profs[0][k], float) else int(np.median([p[k] for p in profs]))) for k in profs[0]}
-    ms = float(np.median(tb)) * 1e3
-    ent = {"wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(min(tb) * 1e3, 4),
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc = lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
+            tb.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise SystemExit("irb_convolve_periodic failed: " + lib.irb_last_error().decode())
+        lib.irb_convolve_profile_events(1)                           # a few more calls with the device-event part of the profile on
+        for _ in range(7):
+            lib.irb_convolve_periodic(dev, xp, Ca, La, hp, Ci, Lh, Bk, 1, op)
+            p = _lib.ConvolveProfile()
+            lib.irb_convolve_last_profile(C.byref(p))
+            profs.append(p.as_dict())
+        lib.irb_convolve_profile_events(0)
+        med = {k: (round(float(np.median([p[k] for p in profs])), 4) if isinstance(profs[0][k], float) else int(np.median([p[k] for p in profs]))) for k in profs[0]}
+        return float(np.median(tb)) * 1e3, min(tb) * 1e3, med
+
+    out = np.zeros((Ca, La + Lh - 1), np.float32)
+    ms, ms_min, med = c_abi(x, h, out)
+    if med["direct"] != 0 or med["registered_ranges"] != 0:
+        raise SystemExit("one-shot default form on pageable buffers must be the staged one")
+    px, ph, pout = pinned_empty(x.shape), pinned_empty(h.shape), pinned_empty(out.shape)
+    px[:], ph[:] = x, h
+    pout[:] = 0
+    pms, pms_min, pmed = c_abi(px, ph, pout)
+    if pmed["direct"] != 1 or pmed["registered_ranges"] != 0 or not np.array_equal(np.asarray(pout), out):
+        raise SystemExit("one-shot direct form on irb_host_alloc buffers: wrong form or other samples than the staged form")
+    pcie = 4 * (Ca * La + Ca * (La + Lh - 1))
+    ent = {"form": "staged (default for pageable buffers)",
+           "wall_ms_python_mirror": round(float(np.median(ta)) * 1e3, 4), "wall_ms_c_abi": round(ms, 4), "wall_ms_c_abi_min": round(ms_min, 4),
            "Msamples_per_s": round(Ca * La / ms / 1e3, 1), "samples": Ca * La, "calls_timed": reps,
-           "pcie_bytes": 4 * (Ca * La + Ca * (La + Lh - 1) + Ci * Lh), "pcie_GBps_both_ways": round(4 * (Ca * La + Ca * (La + Lh - 1)) / ms / 1e6, 2),
+           "pcie_bytes": pcie + 4 * Ci * Lh, "pcie_GBps_both_ways": round(pcie / ms / 1e6, 2),
            "breakdown_ms": med,
+           "direct_pinned": {"wall_ms_c_abi": round(pms, 4), "wall_ms_c_abi_min": round(pms_min, 4), "Msamples_per_s": round(Ca * La / pms / 1e3, 1),
+                             "pcie_GBps_both_ways": round(pcie / pms / 1e6, 2), "breakdown_ms": pmed,
+                             "note": "audio, IR and result in irb_host_alloc memory: the kernels read and write the caller's buffers (no host copy, "
+                                     "nothing registered); result bit-identical to the staged form's (checked here)"},
            "breakdown_note": "irb_convolve_last_profile, medians over 7 further calls with device events on (those calls wait once more per piece, so "
-                             "their total_ms runs a few us above wall_ms_c_abi).  direct=1: the kernels read the caller's audio and impulse response and write the "
-                             "caller's result buffer themselves (registered for the call; no host copy): fft_in_ms (the IR's partition FFTs + the forward "
-                             "FFTs) and fft_out_ms are PCIe-bound, mac_ms is "
-                             "the multiply over ALL blocks of the signal in mac_launches launches (chunks = pieces = multiplies, blocks_per_chunk = "
-                             "blocks per multiply)",
+                             "their total_ms runs a few us above wall_ms_c_abi).  Staged form: `threads` host threads pack the audio into pinned staging "
+                             "(pack_ms / pack_helper_ms) while the device transforms the chunks before (in_chunks launches), one multiply over all blocks "
+                             "of a piece (mac_launches launches; its time is inside fft_in_ms), ONE inverse launch that raises a word in host memory per "
+                             "output chunk (chunks of blocks_per_chunk blocks), copied out by the same threads (unpack_ms / unpack_helper_ms; wait_* = "
+                             "spinning on the words).  Direct form: fft_in_ms (IR partition FFTs + forward FFTs) and fft_out_ms are PCIe-bound, mac_ms "
+                             "the multiply",
            "note": note + "; pageable numpy buffers, wall clock, engine cached from the first call"}
     lib.irb_release_cached_plans()
     return ent

@@ -737,6 +737,20 @@ def test_resident_server_does_not_stall_other_handles():
         assert rel_rms(y[c, :n_done * 256], yr[c]) < RMS_TOL
     assert rel_rms(yo[0], yo_ref[0]) < RMS_TOL
     # ---- phase 2: the audio thread is ONE C call (60 000 callbacks issued and timed inside the library)
+    # Everything phase 2 does has run once by now (phase 1: the other handles' create / prepare / release / one-shot / destroy, the
+    # quiet sections, A's one-launch form while they were open); what has NOT run yet is the C timing loop itself -- warm it with a
+    # quiet section opened and closed under it, so that no first-use cost (code object, first launch of a form, page faults of the
+    # timing buffer) is left for the callbacks that are held to the audio deadline below.
+    lib = _lib.lib()
+    warm = [None]
+    tw = threading.Thread(target=lambda: warm.__setitem__(0, A.time_callbacks(256, 3000)))
+    tw.start()
+    time.sleep(0.005)
+    _lib.check(lib.irb_device_quiet_begin(0))
+    time.sleep(0.002)
+    _lib.check(lib.irb_device_quiet_end(0))
+    tw.join(timeout=60)
+    assert not tw.is_alive() and warm[0] is not None
     us, box = [None], []
 
     def audio_thread_c():
@@ -759,7 +773,8 @@ def test_resident_server_does_not_stall_other_handles():
     cb = us[0].astype(np.float64)
     lines = [f"{k}: {v * 1e3:.2f} ms" for k, v in marks.items()]
     lines.append(f"adapter A, phase 2: {cb.size} callbacks of 256 samples timed in C ({cb.sum() / 1e6:.2f} s, the other handles' work took {t_work:.2f} s of it): "
-                 f"median {np.median(cb):.1f} us, p99 {np.percentile(cb, 99):.1f} us, p99.9 {np.percentile(cb, 99.9):.1f} us, max {cb.max():.1f} us; "
+                 f"median {np.median(cb):.1f} us, p99 {np.percentile(cb, 99):.1f} us, p99.9 {np.percentile(cb, 99.9):.1f} us, max {cb.max():.1f} us "
+                 f"(slowest five: {[(int(i), round(float(cb[i]), 1)) for i in np.argsort(cb)[-5:][::-1]]}); "
                  f"kernel launches {c1[1] - c0[1]} (callbacks served by one launch each while a quiet section was open, server restarts)")
     unprotected = os.environ.get("IRB_DEVICE_QUIET") == "0"      # diagnostic run: quiet sections switched off, times recorded, not asserted
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
@@ -771,9 +786,10 @@ def test_resident_server_does_not_stall_other_handles():
     # a stall behind the server would be its lifetime cap (250 ms) per device-wide wait: dozens of frees -> seconds.  (Phase 1's
     # marks include a fresh box's first-use costs -- code objects, the first large allocations -- so the bound is on phase 2.)
     assert sum(v for k, v in marks.items() if k.startswith("phase 2")) < 2.0 and sum(marks.values()) < 6.0, marks
-    # every callback inside its period at 48 kHz (5333 us); two strays allowed for the host's scheduler (a thread of this test
-    # process preempted on a shared box), none of them anywhere near a server lifetime
-    assert int((cb >= 5333.0).sum()) <= 2 and cb.max() < 100000.0, (int((cb >= 5333.0).sum()), cb.max())
+    # the audio-thread contract (Source/PluginProcessor.cpp:269-562 runs inside the host's period): EVERY callback of phase 2 inside
+    # its 5333 us at 48 kHz -- a missed period is a dropout.  The slowest five go into the message if it fails.
+    worst = np.argsort(cb)[-5:][::-1]
+    assert cb.max() < 5333.0, [(int(i), float(cb[i])) for i in worst]
 
 
 def test_rt_adapter_host_block_larger_than_block_is_causal():
