@@ -123,8 +123,12 @@ struct irb_fdl {
     int2 *h_info = nullptr;                  // pinned staging of d_stream_info
     // staged one-shot call (IRB_FDL_HOST_IO engines that take long calls): chunk-completion counters in device memory and the
     // chunks' words in mapped host memory (one cache line each) that k_ifft_ola_run raises -- see StepArgs::ck_*
-    unsigned *d_ck = nullptr, *h_ck = nullptr, *d_hck = nullptr;
+    unsigned *d_ck = nullptr, *h_ck = nullptr, *d_hck = nullptr;   // two sets of kCkMax each: consecutive pieces of a call alternate
     unsigned ck_seq = 0;
+    // ... and its pipeline over the pieces of a long signal: the forward FFTs of piece k + 1 run on a second stream while piece k's
+    // inverse FFTs leave on the first; events order them around the multiplies
+    hipStream_t stream_in = nullptr;
+    hipEvent_t ev_pipe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // forward FFTs of piece k done [k % 2], multiply of piece k done [2 + k % 2], FDL reset [4]
 };
 
 namespace {
@@ -321,14 +325,15 @@ MfmaPlan mfma_plan(const irb_fdl *h, int T)
     MfmaPlan p;
     const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
     const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);           // every split keeps a few chunks
-    const long slots = (long) h->mfma_wgs * h->mfma_res;                                     // workgroups resident at once
+    const int target = h->mfma_wgs;
+    const long slots = (long) target * h->mfma_res;                                          // workgroups resident at once
     auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, slots / std::max<long>(1, wgs))); };
-    const long per_round = h->mfma_wgs / units;                                              // tiles that give every CU one workgroup
+    const long per_round = target / units;                                                   // tiles that give every CU one workgroup
     auto run = [&](int first, int ntiles) {                                                  // tiles [first, first + ntiles)
         if (ntiles <= 0) return;
         const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
         if (full == 0 || !h->mfma_two_launch) {
-            p.l[p.n++] = {first, ntiles, ntiles * units <= h->mfma_wgs ? splits_for(ntiles * units) : 1};
+            p.l[p.n++] = {first, ntiles, ntiles * units <= target ? splits_for(ntiles * units) : 1};
             return;
         }
         p.l[p.n++] = {first, full, std::min(by_work, h->mfma_res)};
@@ -476,8 +481,9 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
     return IRB_OK;
 }
 
-int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
+int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     irb::StepArgs a = c.a;
     a.t_first = first; a.t_count = count;
     h->n_launches++;
@@ -485,9 +491,9 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count)
         if (first != 0) a.hist_first = -1;                              // (the call's first launch carries the history)
         const int hist_wgs = a.hist_first >= 0 ? h->S * (h->xt_hist / 16) * std::max(1, h->M / 64) : 0;
         FOR_N(h->N, irb::k_push_fft_batch_t<NN><<<dim3(h->S * ((count + irb::PushTGeom<NN>::NBW - 1) / irb::PushTGeom<NN>::NBW) + hist_wgs),
-                                                  dim3(irb::kWave * irb::PushTGeom<NN>::NBW), 0, h->stream>>>(a, h->S));
+                                                  dim3(irb::kWave * irb::PushTGeom<NN>::NBW), 0, stream>>>(a, h->S));
     } else {
-        FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * count + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
+        FOR_N(h->N, irb::k_push_fft_batch<NN><<<dim3((h->S * count + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, stream>>>(a, h->S));
     }
     HIP_TRY(hipGetLastError());
     return IRB_OK;
@@ -541,13 +547,14 @@ int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launch
     return IRB_OK;
 }
 
-int tiled_ifft(irb_fdl *h, const TiledCall &c, int first, int count)      // first: a multiple of OlaGeom::NB
+int tiled_ifft(irb_fdl *h, const TiledCall &c, int first, int count, hipStream_t stream = nullptr)      // first: a multiple of OlaGeom::NB
 {
+    if (!stream) stream = h->stream;
     irb::StepArgs a = c.a;
     a.t_first = first; a.t_count = count;
     h->n_launches++;
     FOR_N(h->N, irb::k_ifft_ola_run<NN, irb::OlaGeom<NN>::NB><<<dim3(h->S * ((count + irb::OlaGeom<NN>::NB - 1) / irb::OlaGeom<NN>::NB)),
-                                                                 dim3(irb::kWave * (irb::OlaGeom<NN>::NB + 1)), 0, h->stream>>>(a, h->S));
+                                                                 dim3(irb::kWave * (irb::OlaGeom<NN>::NB + 1)), 0, stream>>>(a, h->S));
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
@@ -760,7 +767,7 @@ struct StagedPiece {
     long stride = 0;                                   // floats between the channels of the staging
     const float *audio[2] = {nullptr, nullptr};
     float *out[2] = {nullptr, nullptr};
-    float *host_in = nullptr, *host_out = nullptr;
+    float *host_in = nullptr, *host_out = nullptr;     // this piece's half of the staging
     long p0 = 0, La = 0, lim = 0;                      // first block of the piece; samples of audio / of result the call has
     // the IR's samples (first piece only): rows of ir_len floats each; whoever gets to it first copies them -- the helpers look
     // here before anything else, the calling thread only once no audio is left to pack
@@ -780,15 +787,12 @@ struct StagedPiece {
     volatile unsigned *words = nullptr;                // chunk k's word at words[16 k]
     unsigned seq = 0;
     std::atomic<int> unpack_next{0}, unpacked{0};
-    // a call that fails sets gave_up and waits for `active` (helpers inside helper()) to drain before it returns: nothing may touch the
-    // caller's buffers afterwards.  (Both seq_cst: a helper that enters late sees gave_up, one that entered earlier is waited for.)
-    std::atomic<int> gave_up{0}, active{0};
     // per-thread time accounting (index 0 = the calling thread)
     double pack_ms[kCrewMax] = {0}, unpack_ms[kCrewMax] = {0}, wait_ms[kCrewMax] = {0};
 
     bool copy_ir(int who)                              // false: someone else has it
     {
-        if (ir_claimed.exchange(1, std::memory_order_acq_rel)) return false;
+        if (ir_claimed.load(std::memory_order_acquire) || ir_claimed.exchange(1, std::memory_order_acq_rel)) return false;
         const double t0 = now_ms();
         for (int r = 0; r < ir_rows; r++) std::memcpy(ir_stage[r], ir[r], sizeof(float) * (size_t) ir_len);
         ir_done.store(1, std::memory_order_release);
@@ -797,60 +801,105 @@ struct StagedPiece {
     }
     bool pack_one(int who)                             // false: nothing left to claim
     {
+        const int n = (int) item_first.size();
+        if (pack_next.load(std::memory_order_acquire) >= n) return false;
         const int i = pack_next.fetch_add(1, std::memory_order_acq_rel);
-        if (i >= (int) item_first.size()) return false;
+        if (i >= n) return false;
         const double t0 = now_ms();
-        const long s0 = (p0 + item_first[(size_t) i]) * B, n = (long) item_count[(size_t) i] * B;
-        const long have = std::max<long>(0, std::min<long>(n, La - s0));   // the rest of the item is the flush: the kernel reads zeros for it (StepArgs::in_len)
+        const long s0 = (p0 + item_first[(size_t) i]) * B, cnt = (long) item_count[(size_t) i] * B;
+        const long have = std::max<long>(0, std::min<long>(cnt, La - s0));   // the rest of the item is the flush: the kernel reads zeros for it (StepArgs::in_len)
         for (int ch = 0; ch < C; ch++)
             if (have > 0) std::memcpy(host_in + (size_t) ch * stride + (size_t) item_first[(size_t) i] * B, audio[ch] + s0, sizeof(float) * (size_t) have);
         chunk_left[(size_t) item_chunk[(size_t) i]].fetch_sub(1, std::memory_order_acq_rel);
         pack_ms[who] += now_ms() - t0;
         return true;
     }
-    void unpack_all(int who)
+    int claim_chunk()                                  // an output chunk nobody has yet, -1: none left
     {
-        for (;;) {
-            if (gave_up.load()) return;
-            const int k = unpack_next.fetch_add(1, std::memory_order_acq_rel);
-            if (k >= nout) return;
+        if (unpack_next.load(std::memory_order_acquire) >= nout) return -1;
+        const int k = unpack_next.fetch_add(1, std::memory_order_acq_rel);
+        return k < nout ? k : -1;
+    }
+    bool chunk_ready(int k) const { return __atomic_load_n(words + 16 * (size_t) k, __ATOMIC_ACQUIRE) == seq; }
+    void copy_chunk(int k, int who)
+    {
+        const double t1 = now_ms();
+        const int first = k * ck_blocks, cnt = std::min(ck_blocks, T - first);
+        const long s0 = (p0 + first) * B, n = (long) cnt * B;
+        const long take = std::max<long>(0, std::min<long>(n, lim - s0));
+        for (int ch = 0; ch < C; ch++)
+            if (take > 0) irb_copy_stream_(out[ch] + s0, host_out + (size_t) ch * stride + (size_t) first * B, sizeof(float) * (size_t) take);
+        unpack_ms[who] += now_ms() - t1;
+        unpacked.fetch_add(1, std::memory_order_acq_rel);
+    }
+    bool all_unpacked() const { return unpacked.load(std::memory_order_acquire) >= nout; }
+};
+
+// One staged call = its pieces + what the threads share.  Reference-counted: a helper that wakes up after the call is over finds
+// `finished` set and touches nothing of the call.
+struct StagedCall {
+    std::vector<std::unique_ptr<StagedPiece>> piece;
+    std::atomic<int> open{0};                          // pieces [0, open) may be worked on (their halves of the staging are free)
+    // the call ends (finished) or fails (gave_up: set, then `active` -- helpers inside work() -- is waited for before the failing call
+    // returns: nothing may touch the caller's buffers afterwards).  seq_cst: a helper that enters late sees the flag, one that entered
+    // earlier is waited for.
+    std::atomic<int> finished{0}, gave_up{0}, active{0};
+
+    bool stop() const { return finished.load() || gave_up.load(); }
+    // something to pack in the open pieces?  (the older one first: the device wants it first)
+    bool pack_some(int who)
+    {
+        const int n = open.load(std::memory_order_acquire);
+        for (int k = std::max(0, n - 2); k < n; k++)
+            if (piece[(size_t) k]->copy_ir(who) || piece[(size_t) k]->pack_one(who)) return true;
+        return false;
+    }
+    // the oldest output chunk nobody has: wait for its word (packing whatever turns up meanwhile: the device's input must not starve
+    // behind a thread that waits for its output), copy it out.  false: no chunk left in the open pieces.
+    // (only_ready: take a chunk only if its word is there already -- the calling thread between its launches)
+    bool unpack_some(int who, int &oldest, bool only_ready = false)
+    {
+        const int n = open.load(std::memory_order_acquire);
+        while (oldest < n && piece[(size_t) oldest]->unpack_next.load(std::memory_order_acquire) >= piece[(size_t) oldest]->nout) oldest++;
+        for (int k = oldest; k < n; k++) {
+            StagedPiece &p = *piece[(size_t) k];
+            if (only_ready) {
+                const int nx = p.unpack_next.load(std::memory_order_acquire);
+                if (nx >= p.nout || !p.chunk_ready(nx)) continue;
+            }
+            const int c = p.claim_chunk();
+            if (c < 0) continue;
             const double t0 = now_ms();
-            volatile unsigned *w = words + 16 * (size_t) k;
             timespec ts0;
             clock_gettime(CLOCK_MONOTONIC, &ts0);
-            for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; spins++) {
+            for (unsigned spins = 0; !p.chunk_ready(c); spins++) {
+                if (gave_up.load(std::memory_order_relaxed)) return true;
+                if ((spins & 63u) == 63u && pack_some(who)) continue;
                 __builtin_ia32_pause();
-                if (gave_up.load(std::memory_order_relaxed)) break;
                 if ((spins & 4095u) == 4095u) {
                     timespec ts1;
                     clock_gettime(CLOCK_MONOTONIC, &ts1);
-                    if ((ts1.tv_sec - ts0.tv_sec) * 1000000000L + (ts1.tv_nsec - ts0.tv_nsec) > kSpinLimitNs) { gave_up.store(1); break; }
+                    if ((ts1.tv_sec - ts0.tv_sec) * 1000000000L + (ts1.tv_nsec - ts0.tv_nsec) > kSpinLimitNs) { gave_up.store(1); return true; }
                 }
             }
-            const double t1 = now_ms();
-            if (!gave_up.load(std::memory_order_relaxed)) {
-                const int first = k * ck_blocks, cnt = std::min(ck_blocks, T - first);
-                const long s0 = (p0 + first) * B, n = (long) cnt * B;
-                const long take = std::max<long>(0, std::min<long>(n, lim - s0));
-                for (int ch = 0; ch < C; ch++)
-                    if (take > 0) irb_copy_stream_(out[ch] + s0, host_out + (size_t) ch * stride + (size_t) first * B, sizeof(float) * (size_t) take);
-            }
-            wait_ms[who] += t1 - t0;
-            unpack_ms[who] += now_ms() - t1;
-            unpacked.fetch_add(1, std::memory_order_acq_rel);
+            p.wait_ms[who] += now_ms() - t0;
+            p.copy_chunk(c, who);
+            return true;
         }
+        return false;
     }
-    void helper(int who)
+    void work(int who)                                 // a helper thread's life inside one call
     {
         active.fetch_add(1);
-        if (!gave_up.load()) {
-            (void) copy_ir(who);
-            while (!gave_up.load() && pack_one(who)) { }
-            unpack_all(who);
+        int oldest = 0;
+        while (!stop()) {
+            if (pack_some(who)) continue;
+            if (unpack_some(who, oldest)) continue;
+            __builtin_ia32_pause();
         }
         active.fetch_sub(1);
     }
-    void abandon()                                     // the call has failed: no helper is inside this piece when this returns
+    void abandon()                                     // the call has failed: no helper is inside it when this returns
     {
         gave_up.store(1);
         timespec t0;
@@ -870,16 +919,16 @@ struct Crew {
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv;
-    std::shared_ptr<StagedPiece> cur;
+    std::shared_ptr<StagedCall> cur;
     std::atomic<unsigned long long> gen{0};
     bool quit = false;
-    long linger_ns = 150000;                           // a helper that has finished a piece keeps looking for the next one this long before it
+    long linger_ns = 150000;                           // a helper that has finished a call keeps looking for the next one this long before it
                                                        // sleeps: calls in a row (a batch render) do not pay a thread wake-up each (~40 us)
     void run(int who)
     {
         unsigned long long seen = 0;
         for (;;) {
-            std::shared_ptr<StagedPiece> p;
+            std::shared_ptr<StagedCall> p;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return quit || gen.load(std::memory_order_acquire) != seen; });
@@ -887,7 +936,7 @@ struct Crew {
                 seen = gen.load(std::memory_order_acquire);
                 p = cur;
             }
-            if (p) p->helper(who);
+            if (p) p->work(who);
             p.reset();
             timespec t0;
             clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -909,7 +958,7 @@ struct Crew {
         } catch (...) { }                              // no more threads to be had: the caller works with the ones there are
         return (int) th.size();
     }
-    void post(std::shared_ptr<StagedPiece> p)
+    void post(std::shared_ptr<StagedCall> p)
     {
         { std::lock_guard<std::mutex> lk(mu); cur = std::move(p); gen.fetch_add(1, std::memory_order_acq_rel); }
         cv.notify_all();
@@ -917,7 +966,7 @@ struct Crew {
     void stop()
     {
         if (th.empty()) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; cur.reset(); }
+        { std::lock_guard<std::mutex> lk(mu); quit = true; if (cur) cur->finished.store(1); cur.reset(); }
         cv.notify_all();
         for (auto &t : th) t.join();
         th.clear();
@@ -927,7 +976,7 @@ struct Crew {
 
 struct OfflineEngineGuard {
     irb_fdl *eng = nullptr;                            // created with IRB_FDL_HOST_IO: its mapped pinned staging [input | output][C][Tmax*B] is what the kernels read and write
-    std::vector<hipEvent_t> ev;                        // [0..3]: phase boundaries (timing)
+    std::vector<hipEvent_t> ev;                        // phase boundaries of the pieces (timing; created on first use): 4 per piece
     Crew crew;
     irb_convolve_profile prof;
     bool have_prof = false;
@@ -947,7 +996,8 @@ struct OfflineEngineGuard {
 };
 thread_local OfflineEngineGuard g_offline;
 std::atomic<bool> g_offline_profile_events{false};     // irb_convolve_profile_events(): read the chunks' device events into the profile
-constexpr int kOfflineMaxBlocks = 16384;                  // blocks per multiply: longer signals go through in several (the FDL carries over)
+constexpr int kOfflineMaxBlocks = 8192;                   // blocks per piece at most (two pieces' staging exist side by side)
+constexpr int kOfflineTimedPieces = 16;                   // pieces whose phases the device-event profile follows one by one
 }
 
 extern "C" {
@@ -972,6 +1022,8 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->h_done) (void) hipHostFree(h->h_done);
     if (h->h_ck) (void) hipHostFree(h->h_ck);
     (void) hipFree(h->d_ck);
+    if (h->stream_in) { (void) hipStreamSynchronize(h->stream_in); (void) hipStreamDestroy(h->stream_in); }
+    for (auto &e : h->ev_pipe) if (e) (void) hipEventDestroy(e);
     if (h->bar_in) (void) hipFree(h->bar_in);
     if (h->rt_stream) (void) hipStreamDestroy(h->rt_stream);
     if (h->h_io) (void) hipHostFree(h->h_io);
@@ -1103,14 +1155,17 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         *h->h_status = 0;
         *h->h_done = 0;
         if (h->host_io && !h->stepwise) {                 // the one-shot function's engine
-            if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ck), sizeof(unsigned) * 16 * kCkMax, hipHostMallocMapped)) != hipSuccess ||
+            if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ck), sizeof(unsigned) * 16 * 2 * kCkMax, hipHostMallocMapped)) != hipSuccess ||
                 (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hck), h->h_ck, 0)) != hipSuccess ||
-                (e = hipMalloc(reinterpret_cast<void **>(&h->d_ck), sizeof(unsigned) * kCkMax)) != hipSuccess ||
-                (e = hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * kCkMax, h->stream)) != hipSuccess) {
+                (e = hipMalloc(reinterpret_cast<void **>(&h->d_ck), sizeof(unsigned) * 2 * kCkMax)) != hipSuccess ||
+                (e = hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * 2 * kCkMax, h->stream)) != hipSuccess ||
+                (e = hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking)) != hipSuccess) {
                 rc = fail(IRB_ERR_HIP, "chunk words: %s", hipGetErrorString(e));
                 break;
             }
-            std::memset(h->h_ck, 0, sizeof(unsigned) * 16 * kCkMax);
+            for (auto &ev : h->ev_pipe) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "pipeline events: %s", hipGetErrorString(e)); break; }
+            std::memset(h->h_ck, 0, sizeof(unsigned) * 16 * 2 * kCkMax);
         }
         if (h->host_io && h->stepwise && env_int("IRB_RT_BAR", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
             int large_bar = 0;
@@ -1733,18 +1788,91 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     clear_out(lim);                                                                 // the dropped tail stays 0 (:236-238)
 
     // ---- the pipeline ---------------------------------------------------------------------------------------------------
-    // ONE multiply-accumulate over all blocks of the signal (the shape the matrix-core kernel is best at: every IR tap is loaded
-    // once per 256 outputs), with the signal moved in and out in chunks around it:
-    //   calling thread : pack chunk k of the audio into pinned memory, launch the forward FFTs of its blocks (the kernel reads the
-    //                    pinned staging over PCIe, no copy command) ... launch the multiply ... launch the inverse FFTs + overlap-add
-    //                    of chunk k (the kernel writes the pinned staging) + an event, for every k
-    //   both threads   : wait for chunk k's event, copy its samples to the caller's buffer (even chunks here, odd chunks on the
-    //                    unpacking thread: that copy is the longest single item of a call)
-    // Signals of more than kOfflineMaxBlocks blocks repeat this per piece; the FDL (ring and overlap) carries over.
+    // The signal goes through in PIECES: per piece the forward FFTs of its blocks ("in": the samples come over PCIe), ONE
+    // multiply-accumulate over all of its blocks (the shape the matrix-core kernel is best at), the inverse FFTs + overlap-add ("out":
+    // the result leaves over PCIe); the FDL (ring, overlap, the matrix cores' history columns) carries from piece to piece.  Where there
+    // are several pieces, piece k + 1's "in" runs on a second stream while piece k's "out" still leaves on the first:
+    //     stream_in :  in(0)            in(1)            in(2)      ...        in(k + 1) waits for mul(k): the multiply reads what in() writes
+    //     stream    :        mul(0) out(0)   mul(1) out(1)   mul(2) out(2)      mul(k) waits for in(k)
+    // Where the samples are: in the caller's own buffers when those are HIP host memory ("direct form"), else in the engine's pinned
+    // staging, two pieces side by side, filled and emptied by the threads of StagedCall ("staged form", the default for pageable memory).
     const double t_begin = now_ms();
     irb_convolve_profile prof;
     std::memset(&prof, 0, sizeof prof);
-    const int Tneed = (int) std::min<long>(steps, std::max(2, dbg_int("offline_max_blocks", kOfflineMaxBlocks)));   // (override: tests run several pieces on small signals)
+    // ---- direct or staged?  Direct ONLY for buffers that are HIP host memory already (irb_host_alloc / hipHostMalloc, or registered by
+    // the caller), or when the caller has opted in to the per-call registration of pageable memory (IRB_OFFLINE_DIRECT=1; exposure:
+    // INTEGRATION.md section 1, profiles/NOTES.md "Two wrong one-shot results").
+    const DirectMode mode = direct_mode_from_env();
+    std::unique_ptr<DeviceQuiet> quiet;
+    HostRanges ranges, ir_ranges;
+    bool direct = false, ir_direct = false;
+    float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
+    const float *d_irp[2] = {nullptr, nullptr};
+    if (mode != DirectMode::kNever && steps >= 2) {
+        const double t_reg = now_ms();
+        if (mode == DirectMode::kRegister) {
+            // (registering and unregistering host memory are device-wide operations for the runtime: with a resident real-time server
+            // alive on the device the call waited until that server's callbacks stopped, so the registering form sits in a quiet section)
+            quiet.reset(new DeviceQuiet(device));
+            ranges.add(audio, audio_ch, (size_t) La);
+            ranges.add(out, audio_ch, (size_t) Lout);
+            ranges.add(ir, ir_ch, (size_t) Lh_eff);
+            direct = ir_direct = ranges.commit(true);
+            if (!direct) {                                           // (a read-only mapping of the IR is refused: the staged IR set-up serves then)
+                ranges.release();
+                ranges.add(audio, audio_ch, (size_t) La);
+                ranges.add(out, audio_ch, (size_t) Lout);
+                direct = ranges.commit(true);
+            }
+        } else {
+            ranges.add(audio, audio_ch, (size_t) La);
+            ranges.add(out, audio_ch, (size_t) Lout);
+            direct = ranges.commit(false);
+            if (direct) { ir_ranges.add(ir, ir_ch, (size_t) Lh_eff); ir_direct = ir_ranges.commit(false); }
+        }
+        for (int c = 0; c < audio_ch && direct; c++) {
+            d_audio[c] = ranges.dev(audio[c]);
+            d_res[c] = ranges.dev(out[c]);
+            direct = d_audio[c] && d_res[c];
+        }
+        for (int c = 0; c < ir_ch && direct && ir_direct; c++) {
+            d_irp[c] = (mode == DirectMode::kRegister ? ranges : ir_ranges).dev(ir[c]);
+            if (!d_irp[c]) ir_direct = false;
+        }
+        if (!direct) { ranges.release(); ir_ranges.release(); quiet.reset(); }   // not HIP host memory (or a registration refused): the staged form
+        else { prof.register_ms = now_ms() - t_reg; prof.registered_ranges = ranges.n_registered; }
+    }
+    auto release_ranges = [&]() { ranges.release(); ir_ranges.release(); quiet.reset(); direct = ir_direct = false; };
+
+    // ---- how the signal is cut into pieces.  One piece wherever it fits: a piece costs the multiply a whole round of workgroups and the
+    // pipeline two cross-stream waits, and the link carries only ~1.4x as much both ways as one way (profiles/r05_oneshot_pieces.txt).
+    // The exception is the STAGED form of link-bound signals (configs[1]: 0.03 ms of multiply in 0.3 ms): two pieces, so that the host
+    // packs the second under the first one's multiply and unpacking (0.338 -> 0.306 ms).  Estimates: 100 TFLOP/s of the four-product
+    // count, 50 GB/s one way.
+    std::vector<int> piece_T;
+    auto plan_pieces = [&]() {
+        piece_T.clear();
+        // (staged: two pieces' staging exist side by side; override: tests run many pieces on small signals)
+        const long cap = std::max(2, dbg_int("offline_max_blocks", direct ? 2 * kOfflineMaxBlocks : kOfflineMaxBlocks));
+        const long piece_min = std::max<long>(256, (1L << 18) / B);                        // a piece worth its launches: a MiB of samples per channel
+        const double mac_us = 8.0 * P * (fft_len_for_block(B) / 2) * (double) steps * audio_ch / 1e8, io_us = 4.0 * ((double) La + (double) Lout) * audio_ch / 5e4;
+        long n = 1;
+        if (!direct && steps >= 2 * piece_min && mac_us < 0.6 * io_us) n = 2;
+        n = std::max(1, dbg_int("offline_pieces", (int) n));
+        long Tp = (steps + n - 1) / n;
+        if (Tp >= 256) Tp = (Tp + 255) / 256 * 256;                                        // whole tiles of the matrix-core kernel
+        Tp = std::min(Tp, cap);
+        for (long done = 0; done < steps; done += Tp) piece_T.push_back((int) std::min(Tp, steps - done));
+        if (piece_T.size() >= 2 && piece_T.back() == 1 && Tp >= 3) { piece_T[piece_T.size() - 2] -= 1; piece_T.back() = 2; }   // (a one-block piece is a plain step: not in the pipeline)
+    };
+    plan_pieces();
+    {
+        bool one_block_piece = false;
+        for (int T : piece_T) one_block_piece |= T == 1;
+        if (direct && one_block_piece) { release_ranges(); plan_pieces(); }              // (tests that force two-block pieces: a plain step reads whole blocks)
+    }
+    const int n_pieces = (int) piece_T.size(), Tp = piece_T[0];
+    const int Tneed = std::max(2, n_pieces > 1 ? 2 * Tp : Tp);         // blocks of staging per channel (>= 2: a one-block engine would be a stepwise one, without the pipeline's streams)
     // the calling thread's previous engine is reused when it is large enough: creating one (device and pinned
     // allocations) costs ~100x the kernels of a typical call.  irb_release_cached_plans() frees it.
     irb_fdl *h = g_offline.eng;
@@ -1758,33 +1886,38 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         int rc0 = irb_fdl_create(&cfg, &h);
         if (rc0 != IRB_OK) { clear_out(0); return rc0; }
         g_offline.eng = h;
-        hipError_t e = hipSuccess;
-        g_offline.ev.assign(4, nullptr);
-        for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&g_offline.ev[k]);
-        if (e != hipSuccess) { g_offline.release(); clear_out(0); return fail(IRB_ERR_HIP, "offline events: %s", hipGetErrorString(e)); }
         prof.engine_created = 1;
     }
     OfflineEngineGuard &g = g_offline;
     // every error return from here on: nothing of the call may still be reading the staging or writing the result, and the result
     // is the cleared buffer the reference returns when it gives up (:39-42) -- never a half-written one
-    std::shared_ptr<StagedPiece> live;                                  // the piece the helper threads may be working on
+    std::shared_ptr<StagedCall> sc;                                     // what the helper threads may be working on
     auto bail = [&](int code) {
         char keep[sizeof g_err];
         std::memcpy(keep, g_err, sizeof keep);
-        if (live) live->abandon();
+        if (sc) sc->abandon();
+        (void) hipStreamSynchronize(h->stream_in);
         (void) irb_sync(h);
-        if (h->d_ck) { (void) hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * kCkMax, h->stream); (void) irb_sync(h); }   // (a piece that died half-way leaves counts behind)
+        (void) hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * 2 * kCkMax, h->stream);   // (a piece that died half-way leaves counts behind)
+        (void) irb_sync(h);
+        (void) hipGetLastError();
         clear_out(0);
         std::memcpy(g_err, keep, sizeof keep);
         return code;
     };
     int rc = IRB_OK;
     const bool device_times = g_offline_profile_events;
+    if (device_times) {
+        const size_t want = (size_t) 5 * std::min(n_pieces, kOfflineTimedPieces);
+        while (g.ev.size() < want) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return bail(fail(IRB_ERR_HIP, "offline events"));
+            g.ev.push_back(e);
+        }
+    }
     // The IR's set-up is ONE launch that transforms the samples where they lie (k_ir_fft_direct: partition FFTs, zero rows, stream
-    // records) + the tap-contiguous copy for the matrix cores.  "Where they lie" is the engine's pinned IR staging unless the caller's IR
-    // is device-visible itself (direct form).  It goes on the engine's stream BEHIND the first forward-FFT launch: the device does
-    // not overlap the two anyway (profiles/r04_oneshot_timeline.txt), and the host's copy of the IR into the staging then happens
-    // while the device already pulls audio over PCIe.
+    // records) + the tap-contiguous copy for the matrix cores, on the multiply's stream in front of the first multiply.  "Where they
+    // lie" is the engine's pinned IR staging unless the caller's IR is device-visible itself.
     bool ir_started = false;
     float *ir_stage[2] = {h->h_ir, h->h_ir + (size_t) h->P * h->B};             // (h_ir holds 2 C P B floats: two rows of any IR this engine takes)
     const float *ir_stage_dev[2] = {h->d_hir, h->d_hir + (size_t) h->P * h->B};
@@ -1794,284 +1927,233 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         for (int r = 0; r < ir_ch; r++) std::memcpy(ir_stage[r], ir[r], sizeof(float) * (size_t) Lh_eff);
         return launch_ir_from_staging();
     };
-    // ---- direct form: the kernels read the caller's audio and write the caller's result buffer themselves: no host copy at all, one
-    // launch per phase.  ONLY for buffers that are HIP host memory already (irb_host_alloc / hipHostMalloc, or registered by the
-    // caller), or when the caller has opted in to the per-call registration of pageable memory (IRB_OFFLINE_DIRECT=1; exposure:
-    // INTEGRATION.md section 1, profiles/NOTES.md "Two wrong one-shot results").
-    const DirectMode mode = direct_mode_from_env();
-    const bool last_piece_is_one_block = steps > 1 && steps % Tneed == 1;
-    if (mode != DirectMode::kNever && steps >= 2 && !last_piece_is_one_block) {
-        const double t_reg = now_ms();
-        // (registering and unregistering host memory are device-wide operations for the runtime: with a resident real-time server
-        // alive on the device the call waited until that server's callbacks stopped, so the registering form sits in a quiet section)
-        std::unique_ptr<DeviceQuiet> quiet;
-        HostRanges ranges, ir_ranges;
-        bool ok = false, ir_direct = false;
-        if (mode == DirectMode::kRegister) {
-            quiet.reset(new DeviceQuiet(device));
-            ranges.add(audio, audio_ch, (size_t) La);
-            ranges.add(out, audio_ch, (size_t) Lout);
-            ranges.add(ir, ir_ch, (size_t) Lh_eff);
-            ok = ir_direct = ranges.commit(true);
-            if (!ok) {                                               // (a read-only mapping of the IR is refused: the staged set-up serves then)
-                ranges.release();
-                ranges.add(audio, audio_ch, (size_t) La);
-                ranges.add(out, audio_ch, (size_t) Lout);
-                ok = ranges.commit(true);
-            }
-        } else {
-            ranges.add(audio, audio_ch, (size_t) La);
-            ranges.add(out, audio_ch, (size_t) Lout);
-            ok = ranges.commit(false);
-            if (ok) { ir_ranges.add(ir, ir_ch, (size_t) Lh_eff); ir_direct = ir_ranges.commit(false); }
-        }
-        float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
-        const float *d_irp[2] = {nullptr, nullptr};
-        for (int c = 0; c < audio_ch && ok; c++) {
-            d_audio[c] = ranges.dev(audio[c]);
-            d_res[c] = ranges.dev(out[c]);
-            ok = d_audio[c] && d_res[c];
-        }
-        for (int c = 0; c < ir_ch && ok && ir_direct; c++) {
-            d_irp[c] = (mode == DirectMode::kRegister ? ranges : ir_ranges).dev(ir[c]);
-            if (!d_irp[c]) ir_direct = false;
-        }
-        const long in_stride = audio_ch == 2 && ok ? (long) (d_audio[1] - d_audio[0]) : 0, out_stride = audio_ch == 2 && ok ? (long) (d_res[1] - d_res[0]) : 0;
-        if (ok) {
-            prof.register_ms = now_ms() - t_reg;
-            prof.setup_ms = t_reg - t_begin;
-            prof.registered_ranges = ranges.n_registered;
-            rc = irb_fdl_reset(h);
-            if (rc != IRB_OK) { (void) irb_sync(h); ranges.release(); ir_ranges.release(); return bail(rc); }
-            float dev_ms[4] = {0, 0, 0, 0};
-            int pieces = 0, mac_launches = 1;
-            if (ir_direct) {
-                // the IR transformed where it lies, in FRONT of the forward FFTs: both pull their samples over PCIe, so one after the other
-                // costs the link's time once, and nothing of the IR's set-up is left between the forward FFTs and the multiply
-                if (device_times) (void) hipEventRecord(g.ev[0], h->stream);   // (the profile counts it with the forward FFTs: "in")
-                rc = set_ir_direct(h, d_irp, ir_ch, Lh_eff);
-                ir_started = true;
-            }
-            for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
-                const int T = (int) std::min<long>(Tneed, steps - p0);
-                irb::StepArgs a = step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride);
-                a.out_stride = out_stride;
-                a.in_len = std::max<long>(0, (long) La - p0 * B);           // blocks past the audio's end are the flush: zeros
-                a.out_len = std::max<long>(0, lim - p0 * B);                 // nothing is written past the samples this call produces
-                TiledCall call;
-                rc = tiled_begin(h, a, T, &call);
-                if (rc != IRB_OK) break;
-                mac_launches = call.mfma ? call.plan.n : 1;
-                if (device_times && !(ir_direct && pieces == 0)) (void) hipEventRecord(g.ev[0], h->stream);
-                rc = tiled_push(h, call, 0, T);
-                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[1], h->stream);
-                if (rc == IRB_OK) rc = ir_now();                             // (an IR that is not device-visible: through the staging, behind the first piece's forward FFTs)
-                if (rc == IRB_OK) rc = tiled_mac(h, call);
-                if (rc == IRB_OK && device_times) (void) hipEventRecord(g.ev[2], h->stream);
-                if (rc == IRB_OK) rc = tiled_ifft(h, call, 0, T);
-                if (rc != IRB_OK) break;
-                tiled_end(h, call);
-                if (device_times) {
-                    (void) hipEventRecord(g.ev[3], h->stream);
-                    if (hipEventSynchronize(g.ev[3]) == hipSuccess) {
-                        float ms = 0;
-                        if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;
-                        if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;
-                        if (hipEventElapsedTime(&ms, g.ev[2], g.ev[3]) == hipSuccess) dev_ms[2] += ms;
-                        if (hipEventElapsedTime(&ms, g.ev[0], g.ev[3]) == hipSuccess) dev_ms[3] += ms;
-                    }
-                }
-            }
-            const double t_wait = now_ms();
-            const hipError_t e = irb_sync(h);                        // also on failure: nothing may still be reading or writing the caller's memory
-            prof.wait_ms = now_ms() - t_wait;
-            ranges.release();
-            ir_ranges.release();
-            if (rc != IRB_OK) return bail(rc);
-            if (e != hipSuccess) return bail(fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e)));
-            rc = check_status(h);
-            if (rc != IRB_OK) return bail(rc);
-            prof.total_ms = now_ms() - t_begin;
-            prof.direct = 1;
-            prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = device_times ? dev_ms[1] : -1.0; prof.fft_out_ms = device_times ? dev_ms[2] : -1.0;
-            prof.device_ms = device_times ? dev_ms[3] : -1.0;
-            prof.chunks = pieces; prof.blocks_per_chunk = Tneed; prof.pieces = pieces; prof.steps = (int) steps;
-            prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
-            prof.mac_launches = prof.mac_on_matrix_cores ? mac_launches : 1;
-            prof.threads = 1;
-            g.prof = prof; g.have_prof = true;
-            return IRB_OK;
-        }
-        ranges.release();                                            // not HIP host memory (or a registration refused): the staged form
-        ir_ranges.release();
-    }
-
-    // ---- staged form (the default for pageable buffers): see StagedPiece above
-    const long stride = (long) h->Tmax * h->B;
+    // ---- staged form: the call's shared state, built and handed to the helpers BEFORE anything is asked of the device (they wake
+    // up -- or, lingering from the call before, start at once -- while this thread resets the FDL)
+    const long stride = (long) h->Tmax * h->B;                          // floats between the channels of the staging
     float *const host_in = h->h_io, *const host_out = h->h_io + (size_t) audio_ch * stride;
     float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
-    const int want_threads = std::max(1, std::min(kCrewMax, env_int("IRB_OFFLINE_THREADS", 3)));
-    const long call_bytes = (long) sizeof(float) * ((long) La + Lout) * audio_ch;
-    // (a helper needs tens of microseconds to wake up: calls that move less than a megabyte are over before it would have copied anything)
-    const int helpers = (want_threads > 1 && call_bytes >= dbg_int("offline_helpers_from", 1 << 20)) ? g.crew.ensure(want_threads - 1) : 0;
-    const int fixed_chunk = dbg_int("offline_chunk", 0);               // (tests: every item, launch chunk and output chunk this many blocks)
-    g.crew.linger_ns = 1000L * std::max(0, dbg_int("offline_linger_us", 150));
-    int ola_nb = 4;
-    FOR_N(h->N, ola_nb = irb::OlaGeom<NN>::NB);
-    bool ir_in_piece = false;
-    auto build_piece = [&](long p0, int T) {
-        auto pc = std::make_shared<StagedPiece>();
-        pc->C = audio_ch; pc->B = B; pc->stride = stride; pc->p0 = p0; pc->La = La; pc->lim = lim; pc->T = T;
-        for (int c = 0; c < audio_ch; c++) { pc->audio[c] = audio[c]; pc->out[c] = out[c]; }
-        pc->host_in = host_in; pc->host_out = host_out;
-        // launch chunks: ~256 KiB per channel first, then four times the one before; a remainder shorter than twice the next chunk joins it
-        // (multiples of 16 blocks: the forward-FFT kernels' workgroups).  Items: ~128 KiB per channel.
-        const int c0 = fixed_chunk > 0 ? (fixed_chunk + 15) / 16 * 16 : std::max(16, (65536 / B + 15) / 16 * 16);
-        const int it = fixed_chunk > 0 ? c0 : std::max(16, (32768 / B + 15) / 16 * 16);
-        for (int first = 0, c = c0; first < T; c = fixed_chunk > 0 ? c : 4 * c) {
-            const int cnt = (T - first < 2 * c && fixed_chunk == 0) ? T - first : std::min(c, T - first);
-            pc->in_first.push_back(first); pc->in_count.push_back(cnt);
-            first += cnt;
-        }
-        const int nin = (int) pc->in_first.size();
-        pc->chunk_left.reset(new std::atomic<int>[(size_t) nin]);
-        for (int k = 0; k < nin; k++) {
-            int n_items = 0;
-            for (int f = pc->in_first[(size_t) k], e = f + pc->in_count[(size_t) k]; f < e; f += it, n_items++) {
-                pc->item_first.push_back(f); pc->item_count.push_back(std::min(it, e - f)); pc->item_chunk.push_back(k);
+    int helpers = 0;
+    if (!direct) {
+        const int want_threads = std::max(1, std::min(kCrewMax, env_int("IRB_OFFLINE_THREADS", 3)));
+        const long call_bytes = (long) sizeof(float) * ((long) La + Lout) * audio_ch;
+        // (a helper needs tens of microseconds to wake up: calls that move less than a megabyte are over before it would have copied anything)
+        helpers = (want_threads > 1 && call_bytes >= dbg_int("offline_helpers_from", 1 << 20)) ? g.crew.ensure(want_threads - 1) : 0;
+        const int fixed_chunk = dbg_int("offline_chunk", 0);           // (tests: every item, launch chunk and output chunk this many blocks)
+        g.crew.linger_ns = 1000L * std::max(0, dbg_int("offline_linger_us", 150));
+        int ola_nb = 4;
+        FOR_N(h->N, ola_nb = irb::OlaGeom<NN>::NB);
+        sc = std::make_shared<StagedCall>();
+        long p0 = 0;
+        for (int k = 0; k < n_pieces; p0 += piece_T[(size_t) k], k++) {
+            const int T = piece_T[(size_t) k];
+            std::unique_ptr<StagedPiece> pc(new StagedPiece);
+            const size_t half = n_pieces > 1 ? (size_t) (k & 1) * (size_t) Tp * B : 0;
+            pc->C = audio_ch; pc->B = B; pc->stride = stride; pc->p0 = p0; pc->La = La; pc->lim = lim; pc->T = T;
+            for (int c = 0; c < audio_ch; c++) { pc->audio[c] = audio[c]; pc->out[c] = out[c]; }
+            pc->host_in = host_in + half; pc->host_out = host_out + half;
+            // launch chunks: ~256 KiB per channel first, then four times the one before; a remainder shorter than twice the next chunk joins it
+            // (multiples of 16 blocks: the forward-FFT kernels' workgroups).  Items: ~128 KiB per channel.
+            const int c0 = fixed_chunk > 0 ? (fixed_chunk + 15) / 16 * 16 : std::max(16, (65536 / B + 15) / 16 * 16);
+            const int it = fixed_chunk > 0 ? c0 : std::max(16, (32768 / B + 15) / 16 * 16);
+            for (int first = 0, c = c0; first < T && T > 1; c = fixed_chunk > 0 ? c : 4 * c) {      // (a one-block piece is a plain step on the calling thread: nothing of it is for the helpers)
+                const int cnt = (T - first < 2 * c && fixed_chunk == 0) ? T - first : std::min(c, T - first);
+                pc->in_first.push_back(first); pc->in_count.push_back(cnt);
+                first += cnt;
             }
-            pc->chunk_left[(size_t) k].store(n_items, std::memory_order_relaxed);
+            const int nin = (int) pc->in_first.size();
+            pc->chunk_left.reset(new std::atomic<int>[(size_t) nin]);
+            for (int q = 0; q < nin; q++) {
+                int n_items = 0;
+                for (int f = pc->in_first[(size_t) q], e = f + pc->in_count[(size_t) q]; f < e; f += it, n_items++) {
+                    pc->item_first.push_back(f); pc->item_count.push_back(std::min(it, e - f)); pc->item_chunk.push_back(q);
+                }
+                pc->chunk_left[(size_t) q].store(n_items, std::memory_order_relaxed);
+            }
+            if (k == 0 && T > 1) {                                        // the IR's samples travel with the first piece
+                pc->ir_rows = ir_ch; pc->ir_len = Lh_eff;
+                for (int r = 0; r < ir_ch; r++) { pc->ir[r] = ir[r]; pc->ir_stage[r] = ir_stage[r]; }
+                pc->ir_done.store(0, std::memory_order_relaxed);
+                pc->ir_claimed.store(0, std::memory_order_release);
+            }
+            // output chunks: ~128 KiB per channel (multiples of the inverse-FFT kernel's blocks per workgroup), at most kCkMax
+            int ck = fixed_chunk > 0 ? fixed_chunk : std::max(ola_nb, 32768 / B);
+            ck = (ck + ola_nb - 1) / ola_nb * ola_nb;
+            while ((T + ck - 1) / ck > kCkMax) ck *= 2;
+            pc->ck_blocks = ck; pc->nout = T > 1 ? (T + ck - 1) / ck : 0;   // (a one-block piece is copied out by the calling thread itself)
+            pc->words = h->h_ck + (size_t) 16 * kCkMax * (size_t) (k & 1);
+            if (++h->ck_seq == 0) ++h->ck_seq;                            // (0 is the words' initial value)
+            pc->seq = h->ck_seq;
+            sc->piece.push_back(std::move(pc));
         }
-        if (!ir_started && !ir_in_piece) {                               // the IR's samples travel with the first piece
-            ir_in_piece = true;
-            pc->ir_rows = ir_ch; pc->ir_len = Lh_eff;
-            for (int r = 0; r < ir_ch; r++) { pc->ir[r] = ir[r]; pc->ir_stage[r] = ir_stage[r]; }
-            pc->ir_done.store(0, std::memory_order_relaxed);
-            pc->ir_claimed.store(0, std::memory_order_release);
-        }
-        // output chunks: ~128 KiB per channel (multiples of the inverse-FFT kernel's blocks per workgroup), at most kCkMax
-        int ck = fixed_chunk > 0 ? fixed_chunk : std::max(ola_nb, 32768 / B);
-        ck = (ck + ola_nb - 1) / ola_nb * ola_nb;
-        while ((T + ck - 1) / ck > kCkMax) ck *= 2;
-        pc->ck_blocks = ck; pc->nout = (T + ck - 1) / ck;
-        pc->words = h->h_ck;
-        if (++h->ck_seq == 0) ++h->ck_seq;                                // (0 is the words' initial value)
-        pc->seq = h->ck_seq;
-        return pc;
-    };
-    // the first piece goes to the helpers BEFORE anything is asked of the device: they wake up (or, lingering from the call before, start at once) while
-    // this thread resets the FDL and packs the first chunk
-    std::shared_ptr<StagedPiece> first_piece;
-    {
-        const int T0 = (int) std::min<long>(Tneed, steps);
-        if (T0 > 1) { first_piece = live = build_piece(0, T0); if (helpers > 0) g.crew.post(first_piece); }
+        sc->open.store(std::min(2, n_pieces), std::memory_order_release);   // (the first two pieces' halves of the staging are free from the start: piece 1 is packed while piece 0 is still on its way in)
+        if (helpers > 0) g.crew.post(sc);
     }
+    prof.setup_ms = now_ms() - t_begin - prof.register_ms;
+
     rc = irb_fdl_reset(h);
     if (rc != IRB_OK) return bail(rc);
-    prof.setup_ms = now_ms() - t_begin;
-    double pack_ms[2] = {0, 0}, unpack_ms[2] = {0, 0}, wait_ms[2] = {0, 0}, dev_ms[3] = {0, 0, 0};   // [0] the calling thread, [1] the helpers' sum
-    int pieces = 0, nin_total = 0, nout_total = 0, last_ck = 0;
+    hipStream_t const s_in = h->stream_in, s_mac = h->stream, s_out = h->stream;
+    if (hipEventRecord(h->ev_pipe[4], s_mac) != hipSuccess || hipStreamWaitEvent(s_in, h->ev_pipe[4], 0) != hipSuccess) return bail(fail(IRB_ERR_HIP, "pipeline events"));
+    if (direct && ir_direct) {
+        // the IR transformed where it lies, at once (the first forward FFTs pull audio over the link on the other stream meanwhile)
+        rc = set_ir_direct(h, d_irp, ir_ch, Lh_eff);
+        ir_started = true;
+        if (rc != IRB_OK) return bail(rc);
+    }
+    const long in_stride = direct && audio_ch == 2 ? (long) (d_audio[1] - d_audio[0]) : stride, out_stride = direct && audio_ch == 2 ? (long) (d_res[1] - d_res[0]) : stride;
     auto spin_timed_out = [](const timespec &t0) {
         timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
         return (t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > kSpinLimitNs;
     };
-
-    for (long p0 = 0; p0 < steps && rc == IRB_OK; p0 += Tneed, pieces++) {
-        const int T = (int) std::min<long>(Tneed, steps - p0);
-        irb::StepArgs a = step_args(h, dev_in, dev_out, stride);
-        a.in_len = std::max<long>(0, (long) La - p0 * B);               // blocks past the audio's end are the flush: the kernels read zeros, not the staging
-        a.out_len = std::max<long>(0, lim - p0 * B);
+    // the calling thread copies output chunks too whenever it would otherwise wait: until piece `upto` is out completely
+    int my_oldest = 0;
+    auto unpack_until = [&](int upto) -> int {
+        timespec ts0;
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        for (unsigned spins = 0; !sc->piece[(size_t) upto]->all_unpacked();) {
+            if (sc->gave_up.load()) break;
+            if (sc->unpack_some(0, my_oldest)) continue;
+            __builtin_ia32_pause();                                      // the last chunks are in the helpers' hands
+            if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) sc->gave_up.store(1);
+        }
+        if (!sc->gave_up.load()) return IRB_OK;
+        // a chunk's word never came: a kernel of this call did not finish.  Let the runtime say why, if it knows.
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        return fail(e != hipSuccess ? IRB_ERR_HIP : IRB_ERR_STATE, "one-shot pipeline: an output chunk never arrived (%s)", e != hipSuccess ? hipGetErrorString(e) : "no device error reported");
+    };
+    int mac_launches = 1, nin_total = 0, nout_total = 0, last_ck = 0;
+    long p0 = 0;
+    for (int k = 0; k < n_pieces && rc == IRB_OK; p0 += piece_T[(size_t) k], k++) {
+        const int T = piece_T[(size_t) k];
+        const bool timed = device_times && k < kOfflineTimedPieces;
+        hipEvent_t *tev = timed ? &g.ev[(size_t) 5 * k] : nullptr;
+        StagedPiece *pc = direct ? nullptr : sc->piece[(size_t) k].get();
+        const size_t half = (!direct && n_pieces > 1) ? (size_t) (k & 1) * (size_t) Tp * B : 0;
+        // staged: the halves of the staging this piece uses held piece k - 2: that one must be out completely
+        if (!direct && k >= 2) { rc = unpack_until(k - 2); if (rc != IRB_OK) break; }
+        if (!direct && sc->open.load(std::memory_order_acquire) < k + 1) sc->open.store(k + 1, std::memory_order_release);
+        irb::StepArgs a = direct ? step_args(h, d_audio[0] + p0 * B, d_res[0] + p0 * B, in_stride) : step_args(h, dev_in + half, dev_out + half, stride);
+        a.out_stride = out_stride;
+        a.in_len = std::max<long>(0, (long) La - p0 * B);               // blocks past the audio's end are the flush: the kernels read zeros, not memory
+        a.out_len = std::max<long>(0, lim - p0 * B);                     // nothing is written past the samples this call produces
         if (T == 1) {
-            // a one-block piece (a signal shorter than a block with a one-partition IR, or a last piece of one block): a plain step
+            // a one-block piece (a signal shorter than a block with a one-partition IR; tests that force tiny pieces): a plain step,
+            // outside the pipeline -- everything before it is waited for, staged form only
+            if (k >= 1) { rc = unpack_until(k - 1); if (rc != IRB_OK) break; }
             const long have = std::max<long>(0, std::min<long>(B, (long) La - p0 * B)), take = std::max<long>(0, std::min<long>(B, lim - p0 * B));
             for (int ch = 0; ch < audio_ch; ch++) {
-                float *dst = host_in + (size_t) ch * stride;
+                float *dst = pc->host_in + (size_t) ch * stride;
                 if (have > 0) std::memcpy(dst, audio[ch] + p0 * B, sizeof(float) * (size_t) have);
                 std::fill(dst + have, dst + B, 0.0f);
             }
             rc = ir_now();
+            if (rc == IRB_OK && hipStreamSynchronize(s_in) != hipSuccess) rc = fail(IRB_ERR_HIP, "one-shot convolution: pipeline stream");
             if (rc == IRB_OK) rc = launch_step(h, a);
             if (rc != IRB_OK) break;
             h->t += 1;
             const hipError_t e = irb_sync(h);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e)); break; }
             for (int ch = 0; ch < audio_ch; ch++)
-                if (take > 0) std::memcpy(out[ch] + p0 * B, host_out + (size_t) ch * stride, sizeof(float) * (size_t) take);
+                if (take > 0) std::memcpy(out[ch] + p0 * B, pc->host_out + (size_t) ch * stride, sizeof(float) * (size_t) take);
+            // the next piece's forward FFTs wait for "multiply k done": nothing is pending, the event says so
+            if (hipEventRecord(h->ev_pipe[2 + (k & 1)], h->stream) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventRecord failed"); break; }
             continue;
         }
-        std::shared_ptr<StagedPiece> pc;
-        if (p0 == 0 && first_piece) pc = std::move(first_piece);
-        else { pc = live = build_piece(p0, T); if (helpers > 0) g.crew.post(pc); }
-        const int nin = (int) pc->in_first.size();
-        nin_total += nin; nout_total += pc->nout; last_ck = pc->ck_blocks;
         TiledCall call;
         rc = tiled_begin(h, a, T, &call);
         if (rc != IRB_OK) break;
-        if (device_times) (void) hipEventRecord(g.ev[0], h->stream);
-        // ---- in: launch every chunk's forward FFTs as soon as it and its predecessors are packed; pack when there is nothing to launch
-        timespec ts0;
-        clock_gettime(CLOCK_MONOTONIC, &ts0);
-        unsigned spins = 0;
-        for (int launched = 0; rc == IRB_OK;) {
-            while (launched < nin && rc == IRB_OK && pc->chunk_left[(size_t) launched].load(std::memory_order_acquire) == 0) {
-                rc = tiled_push(h, call, pc->in_first[(size_t) launched], pc->in_count[(size_t) launched]);
-                launched++;
+        mac_launches = call.mfma ? call.plan.n : 1;
+        // ---- in, on stream_in: behind the multiply of the piece before (it reads the columns these kernels write)
+        if (k >= 1 && hipStreamWaitEvent(s_in, h->ev_pipe[2 + ((k - 1) & 1)], 0) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        if (timed) (void) hipEventRecord(tev[0], s_in);
+        if (direct) {
+            rc = tiled_push(h, call, 0, T, s_in);
+            if (rc == IRB_OK) rc = ir_now();                              // (an IR that is not device-visible: through the staging)
+        } else {
+            // launch every chunk's forward FFTs as soon as it and its predecessors are packed; pack when there is nothing to launch
+            const int nin = (int) pc->in_first.size();
+            nin_total += nin; nout_total += pc->nout; last_ck = pc->ck_blocks;
+            timespec ts0;
+            clock_gettime(CLOCK_MONOTONIC, &ts0);
+            unsigned spins = 0;
+            for (int launched = 0; rc == IRB_OK;) {
+                while (launched < nin && rc == IRB_OK && pc->chunk_left[(size_t) launched].load(std::memory_order_acquire) == 0) {
+                    rc = tiled_push(h, call, pc->in_first[(size_t) launched], pc->in_count[(size_t) launched], s_in);
+                    launched++;
+                }
+                if (rc == IRB_OK && !ir_started && pc->ir_done.load(std::memory_order_acquire)) rc = launch_ir_from_staging();
+                if (rc != IRB_OK || (launched == nin && ir_started)) break;
+                if (pc->pack_one(0)) continue;
+                if (pc->copy_ir(0)) continue;                              // (no audio left to claim: the IR, unless a helper has it)
+                if (k >= 1 && sc->unpack_some(0, my_oldest, true)) continue;   // (... or an output chunk of the piece before that has arrived)
+                __builtin_ia32_pause();                                    // a helper is still copying what comes next
+                if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) rc = fail(IRB_ERR_STATE, "one-shot pipeline: a packing thread never finished its chunk");
             }
-            if (rc == IRB_OK && !ir_started && pc->ir_done.load(std::memory_order_acquire)) rc = launch_ir_from_staging();
-            if (rc != IRB_OK || (launched == nin && ir_started)) break;
-            if (pc->pack_one(0)) continue;
-            if (pc->copy_ir(0)) continue;                                  // (no audio left to claim: the IR, unless a helper has it)
-            __builtin_ia32_pause();                                        // a helper is still copying what comes next
-            if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) rc = fail(IRB_ERR_STATE, "one-shot pipeline: a packing thread never finished its chunk");
         }
         if (rc != IRB_OK) break;
-        // ---- the multiply over all blocks of the piece
+        if (timed) (void) hipEventRecord(tev[1], s_in);
+        if (hipEventRecord(h->ev_pipe[k & 1], s_in) != hipSuccess || hipStreamWaitEvent(s_mac, h->ev_pipe[k & 1], 0) != hipSuccess) { rc = fail(IRB_ERR_HIP, "pipeline events"); break; }
+        // ---- the multiply over all blocks of the piece, then out (staged: one launch that raises the chunks' words as it goes)
+        if (timed) (void) hipEventRecord(tev[4], s_mac);
         rc = tiled_mac(h, call);
         if (rc != IRB_OK) break;
-        if (device_times) (void) hipEventRecord(g.ev[1], h->stream);
-        // ---- out: one launch; it raises the chunks' words as it goes
-        call.a.ck_cnt = h->d_ck; call.a.ck_flag = h->d_hck; call.a.ck_blocks = pc->ck_blocks; call.a.ck_seq = pc->seq;
-        rc = tiled_ifft(h, call, 0, T);
+        if (hipEventRecord(h->ev_pipe[2 + (k & 1)], s_mac) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventRecord failed"); break; }
+        if (timed) (void) hipEventRecord(tev[2], s_mac);
+        if (!direct) {
+            call.a.ck_cnt = h->d_ck + (size_t) kCkMax * (size_t) (k & 1); call.a.ck_flag = h->d_hck + (size_t) 16 * kCkMax * (size_t) (k & 1);
+            call.a.ck_blocks = pc->ck_blocks; call.a.ck_seq = pc->seq;
+        }
+        rc = tiled_ifft(h, call, 0, T, s_out);
         if (rc != IRB_OK) break;
-        if (device_times) (void) hipEventRecord(g.ev[2], h->stream);
+        if (timed) (void) hipEventRecord(tev[3], s_out);
         tiled_end(h, call);
-        pc->unpack_all(0);
-        clock_gettime(CLOCK_MONOTONIC, &ts0);
-        const double t_stall = now_ms();
-        for (spins = 0; pc->unpacked.load(std::memory_order_acquire) < pc->nout && !pc->gave_up.load(); ) {   // the chunks the helpers claimed
-            __builtin_ia32_pause();
-            if ((++spins & 4095u) == 0 && spin_timed_out(ts0)) { pc->gave_up.store(1); break; }
-        }
-        prof.stall_ms += now_ms() - t_stall;
-        if (pc->gave_up.load()) {
-            // a chunk's word never came: a kernel of this piece did not finish.  Let the runtime say why, if it knows.
-            const hipError_t e = hipStreamSynchronize(h->stream);
-            rc = fail(e != hipSuccess ? IRB_ERR_HIP : IRB_ERR_STATE, "one-shot pipeline: an output chunk never arrived (%s)", e != hipSuccess ? hipGetErrorString(e) : "no device error reported");
-            break;
-        }
-        pack_ms[0] += pc->pack_ms[0]; unpack_ms[0] += pc->unpack_ms[0]; wait_ms[0] += pc->wait_ms[0];
-        for (int w = 1; w < kCrewMax; w++) { pack_ms[1] += pc->pack_ms[w]; unpack_ms[1] += pc->unpack_ms[w]; wait_ms[1] += pc->wait_ms[w]; }
-        if (device_times) {
-            float ms = 0;
-            if (hipEventSynchronize(g.ev[2]) == hipSuccess) {
-                if (hipEventElapsedTime(&ms, g.ev[0], g.ev[1]) == hipSuccess) dev_ms[0] += ms;     // forward FFTs (incl. waiting for the host's packing) + multiply
-                if (hipEventElapsedTime(&ms, g.ev[1], g.ev[2]) == hipSuccess) dev_ms[1] += ms;     // inverse FFTs + overlap-add
-            }
-        }
+    }
+    // ---- the end of the call: direct -- one wait; staged -- the remaining output chunks, with the helpers
+    const double t_wait = now_ms();
+    if (direct) {
+        const hipError_t e = irb_sync(h);                                // also on failure: nothing may still be reading or writing the caller's memory
+        const hipError_t e2 = hipStreamSynchronize(s_in);
+        if (rc == IRB_OK && (e != hipSuccess || e2 != hipSuccess)) rc = fail(IRB_ERR_HIP, "one-shot convolution: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        ranges.release(); ir_ranges.release(); quiet.reset();            // (registered form: the caller's pages are the caller's again)
+        prof.wait_ms = now_ms() - t_wait;
+    } else if (rc == IRB_OK) {
+        for (int k = std::max(0, n_pieces - 2); k < n_pieces && rc == IRB_OK; k++) rc = unpack_until(k);
+        prof.stall_ms = now_ms() - t_wait;
     }
     if (rc != IRB_OK) return bail(rc);
-    live.reset();
+    if (sc) sc->finished.store(1);
     rc = check_status(h);
     if (rc != IRB_OK) return bail(rc);
     prof.total_ms = now_ms() - t_begin;
-    prof.pack_ms = pack_ms[0]; prof.unpack_ms = unpack_ms[0]; prof.unpack_helper_ms = unpack_ms[1]; prof.pack_helper_ms = pack_ms[1];
-    prof.wait_ms = wait_ms[0]; prof.wait_helper_ms = wait_ms[1];
-    prof.fft_in_ms = device_times ? dev_ms[0] : -1.0; prof.mac_ms = -1.0; prof.fft_out_ms = device_times ? dev_ms[1] : -1.0;   // (staged: the multiply is inside fft_in_ms)
-    prof.device_ms = device_times ? dev_ms[0] + dev_ms[1] : -1.0;
-    prof.chunks = nout_total; prof.in_chunks = nin_total; prof.blocks_per_chunk = last_ck; prof.pieces = pieces; prof.steps = (int) steps;
-    prof.mac_on_matrix_cores = use_mfma(h, (int) std::min<long>(Tneed, steps)) ? 1 : 0;
-    prof.mac_launches = prof.mac_on_matrix_cores ? mfma_plan(h, Tneed).n : 1;
+    prof.direct = direct ? 1 : 0;
+    if (sc) {
+        for (auto &pcp : sc->piece) {
+            prof.pack_ms += pcp->pack_ms[0]; prof.unpack_ms += pcp->unpack_ms[0]; prof.wait_ms += pcp->wait_ms[0];
+            for (int w = 1; w < kCrewMax; w++) { prof.pack_helper_ms += pcp->pack_ms[w]; prof.unpack_helper_ms += pcp->unpack_ms[w]; prof.wait_helper_ms += pcp->wait_ms[w]; }
+        }
+    }
+    prof.fft_in_ms = prof.mac_ms = prof.fft_out_ms = prof.device_ms = -1.0;
+    if (device_times) {
+        // sums over the (first kOfflineTimedPieces) pieces; with several pieces the phases of neighbours overlap, so they add up to more than device_ms
+        const int nt = std::min(n_pieces, kOfflineTimedPieces);
+        float in = 0, mac = 0, outp = 0, all = 0, ms = 0;
+        bool okt = hipEventSynchronize(g.ev[(size_t) 5 * (nt - 1) + 3]) == hipSuccess;
+        for (int k = 0; k < nt && okt; k++) {
+            if (piece_T[(size_t) k] == 1) continue;
+            hipEvent_t *tev = &g.ev[(size_t) 5 * k];
+            okt = hipEventElapsedTime(&ms, tev[0], tev[1]) == hipSuccess; in += ms;
+            if (okt) { okt = hipEventElapsedTime(&ms, tev[4], tev[2]) == hipSuccess; mac += ms; }
+            if (okt) { okt = hipEventElapsedTime(&ms, tev[2], tev[3]) == hipSuccess; outp += ms; }
+        }
+        if (okt && piece_T[0] != 1 && piece_T[(size_t) nt - 1] != 1) okt = hipEventElapsedTime(&all, g.ev[0], g.ev[(size_t) 5 * (nt - 1) + 3]) == hipSuccess;
+        (void) hipGetLastError();
+        if (okt) { prof.fft_in_ms = in; prof.mac_ms = mac; prof.fft_out_ms = outp; prof.device_ms = all; }
+    }
+    prof.chunks = direct ? n_pieces : nout_total; prof.in_chunks = direct ? n_pieces : nin_total; prof.blocks_per_chunk = direct ? Tp : last_ck;
+    prof.pieces = n_pieces; prof.steps = (int) steps;
+    prof.mac_on_matrix_cores = use_mfma(h, Tp) ? 1 : 0;
+    prof.mac_launches = prof.mac_on_matrix_cores ? mac_launches : 1;
     prof.helper_thread = helpers > 0 ? 1 : 0;
     prof.threads = 1 + helpers;
     g.prof = prof; g.have_prof = true;
