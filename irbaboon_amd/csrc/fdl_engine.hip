@@ -124,6 +124,7 @@ struct irb_fdl {
     // staged one-shot call (IRB_FDL_HOST_IO engines that take long calls): chunk-completion counters in device memory and the
     // chunks' words in mapped host memory (one cache line each) that k_ifft_ola_run raises -- see StepArgs::ck_*
     unsigned *d_ck = nullptr, *h_ck = nullptr, *d_hck = nullptr;   // two sets of kCkMax each: consecutive pieces of a call alternate
+    unsigned *h_pk = nullptr, *d_hpk = nullptr;                     // the other direction: words the packing threads raise per input item, polled by k_push_fft_batch_t (StepArgs::pk_*)
     unsigned ck_seq = 0;
     // ... and its pipeline over the pieces of a long signal: the forward FFTs of piece k + 1 run on a second stream while piece k's
     // inverse FFTs leave on the first; events order them around the multiplies
@@ -359,6 +360,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.ck_cnt = nullptr; a.ck_flag = nullptr; a.ck_blocks = 1; a.ck_seq = 0;
+    a.pk_flag = nullptr; a.pk_blocks = 16; a.pk_seq = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -782,6 +784,10 @@ struct StagedPiece {
     std::vector<int> in_first, in_count;                           // launch chunks, in blocks
     std::unique_ptr<std::atomic<int>[]> chunk_left;                // items of the chunk not yet packed
     std::atomic<int> pack_next{0};
+    // (matrix-core pieces: ONE forward-FFT launch for the whole piece, launched before anything is packed; its workgroups wait for the
+    // word of their item -- pk_words[16 i] = seq, stored behind the item's samples.  All items then have pk_blocks blocks but the last)
+    volatile unsigned *pk_words = nullptr;
+    int pk_blocks = 0;
     // out
     int T = 0, ck_blocks = 1, nout = 0;
     volatile unsigned *words = nullptr;                // chunk k's word at words[16 k]
@@ -810,10 +816,12 @@ struct StagedPiece {
         const long have = std::max<long>(0, std::min<long>(cnt, La - s0));   // the rest of the item is the flush: the kernel reads zeros for it (StepArgs::in_len)
         for (int ch = 0; ch < C; ch++)
             if (have > 0) std::memcpy(host_in + (size_t) ch * stride + (size_t) item_first[(size_t) i] * B, audio[ch] + s0, sizeof(float) * (size_t) have);
+        if (pk_words) __atomic_store_n(pk_words + 16 * (size_t) i, seq, __ATOMIC_RELEASE);
         chunk_left[(size_t) item_chunk[(size_t) i]].fetch_sub(1, std::memory_order_acq_rel);
         pack_ms[who] += now_ms() - t0;
         return true;
     }
+    bool all_claimed() const { return pack_next.load(std::memory_order_acquire) >= (int) item_first.size(); }
     int claim_chunk()                                  // an output chunk nobody has yet, -1: none left
     {
         if (unpack_next.load(std::memory_order_acquire) >= nout) return -1;
@@ -1021,6 +1029,7 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->h_status) (void) hipHostFree(h->h_status);
     if (h->h_done) (void) hipHostFree(h->h_done);
     if (h->h_ck) (void) hipHostFree(h->h_ck);
+    if (h->h_pk) (void) hipHostFree(h->h_pk);
     (void) hipFree(h->d_ck);
     if (h->stream_in) { (void) hipStreamSynchronize(h->stream_in); (void) hipStreamDestroy(h->stream_in); }
     for (auto &e : h->ev_pipe) if (e) (void) hipEventDestroy(e);
@@ -1157,6 +1166,8 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
         if (h->host_io && !h->stepwise) {                 // the one-shot function's engine
             if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ck), sizeof(unsigned) * 16 * 2 * kCkMax, hipHostMallocMapped)) != hipSuccess ||
                 (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hck), h->h_ck, 0)) != hipSuccess ||
+                (e = hipHostMalloc(reinterpret_cast<void **>(&h->h_pk), sizeof(unsigned) * 16 * 2 * kCkMax, hipHostMallocMapped)) != hipSuccess ||
+                (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&h->d_hpk), h->h_pk, 0)) != hipSuccess ||
                 (e = hipMalloc(reinterpret_cast<void **>(&h->d_ck), sizeof(unsigned) * 2 * kCkMax)) != hipSuccess ||
                 (e = hipMemsetAsync(h->d_ck, 0, sizeof(unsigned) * 2 * kCkMax, h->stream)) != hipSuccess ||
                 (e = hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking)) != hipSuccess) {
@@ -1166,6 +1177,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             for (auto &ev : h->ev_pipe) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
             if (e != hipSuccess) { rc = fail(IRB_ERR_HIP, "pipeline events: %s", hipGetErrorString(e)); break; }
             std::memset(h->h_ck, 0, sizeof(unsigned) * 16 * 2 * kCkMax);
+            std::memset(h->h_pk, 0, sizeof(unsigned) * 16 * 2 * kCkMax);
         }
         if (h->host_io && h->stepwise && env_int("IRB_RT_BAR", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
             int large_bar = 0;
@@ -1846,19 +1858,13 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
 
     // ---- how the signal is cut into pieces.  One piece wherever it fits: a piece costs the multiply a whole round of workgroups and the
     // pipeline two cross-stream waits, and the link carries only ~1.4x as much both ways as one way (profiles/r05_oneshot_pieces.txt).
-    // The exception is the STAGED form of link-bound signals (configs[1]: 0.03 ms of multiply in 0.3 ms): two pieces, so that the host
-    // packs the second under the first one's multiply and unpacking (0.338 -> 0.306 ms).  Estimates: 100 TFLOP/s of the four-product
-    // count, 50 GB/s one way.
     std::vector<int> piece_T;
     auto plan_pieces = [&]() {
         piece_T.clear();
         // (staged: two pieces' staging exist side by side; override: tests run many pieces on small signals)
         const long cap = std::max(2, dbg_int("offline_max_blocks", direct ? 2 * kOfflineMaxBlocks : kOfflineMaxBlocks));
         const long piece_min = std::max<long>(256, (1L << 18) / B);                        // a piece worth its launches: a MiB of samples per channel
-        const double mac_us = 8.0 * P * (fft_len_for_block(B) / 2) * (double) steps * audio_ch / 1e8, io_us = 4.0 * ((double) La + (double) Lout) * audio_ch / 5e4;
-        long n = 1;
-        if (!direct && steps >= 2 * piece_min && mac_us < 0.6 * io_us) n = 2;
-        n = std::max(1, dbg_int("offline_pieces", (int) n));
+        const long n = std::max<long>(1, std::min<long>(dbg_int("offline_pieces", 1), steps / piece_min));   // (tools: the piece-count sweeps of profiles/r05_oneshot_pieces.txt)
         long Tp = (steps + n - 1) / n;
         if (Tp >= 256) Tp = (Tp + 255) / 256 * 256;                                        // whole tiles of the matrix-core kernel
         Tp = std::min(Tp, cap);
@@ -1954,8 +1960,16 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             // launch chunks: ~256 KiB per channel first, then four times the one before; a remainder shorter than twice the next chunk joins it
             // (multiples of 16 blocks: the forward-FFT kernels' workgroups).  Items: ~128 KiB per channel.
             const int c0 = fixed_chunk > 0 ? (fixed_chunk + 15) / 16 * 16 : std::max(16, (65536 / B + 15) / 16 * 16);
-            const int it = fixed_chunk > 0 ? c0 : std::max(16, (32768 / B + 15) / 16 * 16);
-            for (int first = 0, c = c0; first < T && T > 1; c = fixed_chunk > 0 ? c : 4 * c) {      // (a one-block piece is a plain step on the calling thread: nothing of it is for the helpers)
+            int it = fixed_chunk > 0 ? c0 : std::max(16, (32768 / B + 15) / 16 * 16);
+            // (the kernel that waits for the items' words is the matrix-core path's; blocks of whole 128-byte lines: see there)
+            const bool one_launch = T > 1 && use_mfma(h, T) && B % 32 == 0 && dbg_int("offline_in_one_launch", 1) != 0;
+            if (one_launch) {
+                while ((T + it - 1) / it > kCkMax) it *= 2;
+                pc->in_first.push_back(0); pc->in_count.push_back(T);
+                pc->pk_words = h->h_pk + (size_t) 16 * kCkMax * (size_t) (k & 1);
+                pc->pk_blocks = it;
+            }
+            for (int first = 0, c = c0; first < T && T > 1 && !one_launch; c = fixed_chunk > 0 ? c : 4 * c) {      // (a one-block piece is a plain step on the calling thread: nothing of it is for the helpers)
                 const int cnt = (T - first < 2 * c && fixed_chunk == 0) ? T - first : std::min(c, T - first);
                 pc->in_first.push_back(first); pc->in_count.push_back(cnt);
                 first += cnt;
@@ -2077,13 +2091,21 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             timespec ts0;
             clock_gettime(CLOCK_MONOTONIC, &ts0);
             unsigned spins = 0;
-            for (int launched = 0; rc == IRB_OK;) {
+            int launched = 0;
+            if (pc->pk_words) {
+                // one launch for the whole piece, NOW: its workgroups wait for the items' words; this thread packs with the others and is
+                // through when every item has an owner and the IR's transform is on its way
+                call.a.pk_flag = h->d_hpk + (size_t) 16 * kCkMax * (size_t) (k & 1); call.a.pk_blocks = pc->pk_blocks; call.a.pk_seq = pc->seq;
+                rc = tiled_push(h, call, 0, T, s_in);
+                launched = nin;
+            }
+            for (; rc == IRB_OK;) {
                 while (launched < nin && rc == IRB_OK && pc->chunk_left[(size_t) launched].load(std::memory_order_acquire) == 0) {
                     rc = tiled_push(h, call, pc->in_first[(size_t) launched], pc->in_count[(size_t) launched], s_in);
                     launched++;
                 }
                 if (rc == IRB_OK && !ir_started && pc->ir_done.load(std::memory_order_acquire)) rc = launch_ir_from_staging();
-                if (rc != IRB_OK || (launched == nin && ir_started)) break;
+                if (rc != IRB_OK || (launched == nin && ir_started && (!pc->pk_words || pc->all_claimed()))) break;
                 if (pc->pack_one(0)) continue;
                 if (pc->copy_ir(0)) continue;                              // (no audio left to claim: the IR, unless a helper has it)
                 if (k >= 1 && sc->unpack_some(0, my_oldest, true)) continue;   // (... or an output chunk of the piece before that has arrived)

@@ -93,6 +93,12 @@ struct StepArgs {
     unsigned     *ck_cnt, *ck_flag;
     int           ck_blocks;
     unsigned      ck_seq;
+    // k_push_fft_batch_t for the staged one-shot call: ONE launch transforms all blocks of a piece out of pinned host memory that the
+    // host is still filling -- a workgroup waits (bounded) until the word of its item (pk_blocks blocks, a multiple of the workgroup's 16)
+    // in mapped host memory (pk_flag + 16 * item) holds pk_seq, which the packing thread stores behind the item's samples
+    const unsigned *pk_flag;
+    int           pk_blocks;
+    unsigned      pk_seq;
 };
 
 #ifdef IRB_STAMPS

@@ -149,6 +149,25 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     const bool live = j < a.t_first + a.t_count;
     TwiddleStage<N, kWave * NBW> tws;
     tws.load(a.tw);
+    if (a.pk_flag && (long) j0 * a.B < a.in_len) {
+        // staged one-shot call: the host may still be copying this workgroup's samples into the staging.  One lane polls the item's
+        // word over the link (~2 us a look) for at most 2 s of the 100 MHz clock -- a host that died must not leave the grid behind;
+        // what a timed-out workgroup then transforms is wrong and the status word says so.  No cache invalidate behind the wait (an
+        // acquire fence per wave made this kernel twice as slow): the host only uses this form when every block is whole 128-byte
+        // lines, so no line of this workgroup's samples was fetched by anyone before the word was seen (the kernel's start dropped
+        // whatever earlier kernels left).
+        if (threadIdx.x == 0) {
+            const unsigned *w = a.pk_flag + 16 * (size_t) (j0 / a.pk_blocks);
+            unsigned long long t0, t1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+            while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.pk_seq) {
+                __builtin_amdgcn_s_sleep(8);
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+                if (t1 - t0 > 200000000ull) { __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        __syncthreads();
+    }
     if (live) wave_load_block_upto<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, a.in_len - (long) j * a.B, l_buf[wave], lane);
     tws.store(l_tw);
     __syncthreads();

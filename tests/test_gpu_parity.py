@@ -222,9 +222,10 @@ def test_one_shot_calls_never_register_pageable_memory_by_default(monkeypatch):
 
 def test_staged_pipeline_threads_and_chunking(monkeypatch):
     """The staged form's host pipeline: any number of threads (the caller alone, the default three, more), helpers forced onto
-    calls too short to want them, chunks of 16 blocks (hundreds of chunk words per piece, and more chunks than there are words:
-    the chunk size doubles) -- every variant bit-identical to the one-thread call and equal to the oracle; ragged ends, both tail
-    modes, stereo."""
+    calls too short to want them, the forward FFTs as ONE launch that waits for the packing threads' words (the default where the
+    matrix cores multiply and blocks are whole cache lines) or launched chunk by chunk, items / chunks of 16 blocks (hundreds of
+    words per piece, and more chunks than there are words: the chunk size doubles), several pieces on two streams -- every variant
+    bit-identical to the one-thread call and equal to the oracle; ragged ends, both tail modes, stereo."""
     monkeypatch.delenv("IRB_OFFLINE_DIRECT", raising=False)
     for B, Ca, Ci, La, Lh in ((256, 2, 2, 256 * 700 + 77, 256 * 20 + 3), (16, 1, 1, 16 * 20000 + 5, 16 * 30), (128, 2, 1, 50001, 1000)):
         x = np.stack([white_noise(8900 + c, La) for c in range(Ca)])
@@ -238,7 +239,8 @@ def test_staged_pipeline_threads_and_chunking(monkeypatch):
             nwk = min(La + Lh - 1, (La // B + -(-Lh // B)) * B)
             for c in range(Ca):
                 assert rel_rms(y1[c, :nwk], ref[c, :nwk]) < RMS_TOL
-            for threads, dbg in (("3", {}), ("3", {"offline_helpers_from": 0}), ("5", {"offline_helpers_from": 0, "offline_chunk": 16}),
+            for threads, dbg in (("3", {}), ("3", {"offline_helpers_from": 0}), ("3", {"offline_helpers_from": 0, "offline_in_one_launch": 0}),
+                                 ("5", {"offline_helpers_from": 0, "offline_chunk": 16}),
                                  ("2", {"offline_helpers_from": 0, "offline_chunk": 16, "offline_max_blocks": 300})):
                 monkeypatch.setenv("IRB_OFFLINE_THREADS", threads)
                 _dbg(monkeypatch, **dbg)
