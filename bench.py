@@ -689,8 +689,7 @@ def main():
     if host_overhead:
         print(f"bench.py: host wall clock {wall * 1e3:.3f} ms exceeds the device's event time {ev_ms_max:.3f} ms by more than 5 % in {timed_passes} passes: "
               "reported as measured (`value` follows the wall clock)", file=sys.stderr)
-    three = bool(os.environ.get("IRB_SPLIT_3LAUNCH", "0") not in ("", "0"))
-    launches_per_step = 1 if (info.splits <= 1 or not three) else 3
+    launches_per_step = 1
     kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step; the slowest device
     alg_bytes = I * info.algorithmic_bytes_per_block_step          # per launch: I * (8*P*N + 16*B)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9

@@ -42,8 +42,8 @@ extern "C" {
 
 /* irb_fdl_config.flags */
 #define IRB_FDL_FORCE_FUSED   0x1u  /* always one workgroup per stream               */
-#define IRB_FDL_FORCE_SPLIT   0x2u  /* always split the partitions over workgroups   */
-#define IRB_FDL_SPLIT_3LAUNCH 0x4u  /* split path as three launches (no in-kernel hand-off) */
+/*      0x2u, 0x4u: the partition-split kernels of rounds 1-4 (IRB_FDL_FORCE_SPLIT, IRB_FDL_SPLIT_3LAUNCH); removed in round 5 -- no
+ *      heuristic selected them; the values stay unused */
 #define IRB_FDL_NO_PAIRING    0x8u  /* never share IR rows between the two channels of an instance */
 #define IRB_FDL_FORCE_COLS    0x10u /* always the column-sliced single-launch step (k_step_cols)   */
 #define IRB_FDL_HOST_IO       0x20u /* irb_fdl_process / set_ir_partition: kernels read and write mapped pinned host memory directly

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IRB_LIB") or os.path.join(_HERE, "libirbfdl.so")     # IRB_LIB: another build of the same library (A/B measurements)
 
 IRB_OK, IRB_ERR_ARG, IRB_ERR_HIP, IRB_ERR_LAYOUT, IRB_ERR_STATE = 0, -1, -2, -3, -4
-FORCE_FUSED, FORCE_SPLIT, SPLIT_3LAUNCH, NO_PAIRING, FORCE_COLS, HOST_IO, STEPWISE, NO_RT_KERNEL, RESIDENT = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100
+FORCE_FUSED, NO_PAIRING, FORCE_COLS, HOST_IO, STEPWISE, NO_RT_KERNEL, RESIDENT = 0x1, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100
 
 fpp = C.POINTER(C.POINTER(C.c_float))
 fp = C.POINTER(C.c_float)

@@ -7,6 +7,7 @@
 #include "../../include/irb_deconv.h"
 #include "lfft_kernels.hpp"
 #include "host_ranges.hpp"
+#include "irb_env.hpp"
 #include "../../include/irb_fdl.h"
 
 #include <algorithm>
@@ -285,22 +286,20 @@ int irb_lfft_create(int device, int fft_len, int max_batch, irb_lfft **out)
     if (p->M <= 2048) { p->M1 = p->M; p->M2 = 1; }
     else {
         p->M1 = 1 << (m / 2); p->M2 = p->M / p->M1;
-        if (const char *v = std::getenv("IRB_LFFT_LOG_M1")) {            // tuning: another split of M = M1 * M2 (both factors 16..2048)
-            const int l1 = std::atoi(v);
-            if (l1 >= 4 && l1 <= 11 && m - l1 >= 4 && m - l1 <= 11) { p->M1 = 1 << l1; p->M2 = p->M / p->M1; }
-        }
+        const int l1 = dbg_int("lfft_log_m1", 0);                         // tuning (IRB_DEBUG, irb_env.hpp): another split of M = M1 * M2 (both factors 16..2048)
+        if (l1 >= 4 && l1 <= 11 && m - l1 >= 4 && m - l1 <= 11) { p->M1 = 1 << l1; p->M2 = p->M / p->M1; }
     }
     p->logE = std::min(10, ilog2(p->N));
     if (p->M2 > 1) {
         // rows / columns per workgroup: 8 gives 64-byte global pieces; a single 2^20 transform then has only 64-128
         // workgroups for 256 CUs, so small batches take 4 (32-byte pieces, twice the workgroups: latency-bound anyway)
         p->tile_rows = (long) max_batch * std::min(p->M1, p->M2) / 8 >= 256 ? 8 : 4;
-        if (const char *v = std::getenv("IRB_LFFT_TILE")) p->tile_rows = std::atoi(v);     // tuning: 0, 4, 8, 16
+        p->tile_rows = dbg_int("lfft_tile", p->tile_rows);                // tuning: 0, 4, 8, 16
         // fused split passes (2 launches per transform instead of 3) pay while the transform is launch-bound
         // (profiles/r02_lfft_fuse_ab.txt, r03_lfft_ab.txt): both directions up to 2^20 points (round 3: the forward pass takes its
         // split twiddles from the row transform's LDS table and skips the zero fill of the plan's own spectrum buffer)
         p->fuse_split = (p->N <= (1 << 20) ? 1 : 0) | (p->N <= (1 << 20) ? 2 : 0);
-        if (const char *v = std::getenv("IRB_LFFT_FUSE_SPLIT")) p->fuse_split = std::atoi(v);
+        p->fuse_split = dbg_int("lfft_fuse_split", p->fuse_split);
         if (p->tile_rows == 16 && std::max(p->M1, p->M2) > 1024) p->tile_rows = 8;
     }
     const int E = 1 << p->logE;

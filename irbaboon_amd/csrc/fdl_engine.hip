@@ -6,6 +6,7 @@
 #include "../../include/irb_fdl.h"
 #include "fdl_kernels.hpp"
 #include "host_ranges.hpp"
+#include "irb_env.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -59,17 +60,11 @@ struct irb_fdl {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int I = 0, C = 0, S = 0, B = 0, N = 0, M = 0, P = 0, R = 0, Tmax = 1, splits = 1;
     int Ppad = 0;                            // H rows allocated per set: P rounded up to the time tile
-    int tiled_splits_override = 0;           // tuning: IRB_TILED_SPLITS, read once at create
     bool tiled1 = false;                     // one-bin-per-lane tiled MAC for HBM-sized batches (override: IRB_TILED1)
-    int tiled_kernel = 1;                    // time-tiled MAC: 1 k_cmac_tiled_pk (16 outputs x 8 partitions per step), 0 round 2's k_cmac_tiled<N,8> (IRB_TILED_KERNEL: A/B, tests)
-    int tileTT = 16;                         // outputs per time tile of that kernel
     bool tile8_fused = true;                 // calls of <= 8 blocks with one workgroup per stream: one launch (k_tile8_fused; IRB_TILED_FUSED8=0: the three-launch form)
     int mfma_min_T = 256;                    // calls of at least this many blocks multiply on the matrix cores (k_cmac_mfma); 0 = never (IRB_TILED_MFMA_MIN_T)
     int mfma_min_chunks = 6;                 // Toeplitz chunks (16 partitions each) a split keeps at least (IRB_TILED_MFMA_MIN_CHUNKS)
     int mfma_wgs = 256;                      // workgroups its partition splits aim for (IRB_TILED_MFMA_WGS)
-    int mfma_res = 1;                        // workgroups of it a CU holds at once (IRB_TILED_MFMA_RES)
-    bool mfma_two_launch = true;             // whole rounds of workgroups + a second launch for the remaining tiles (IRB_TILED_MFMA_TWO_LAUNCH)
-    bool mfma_one_grid = true;               // ... both carried by one grid (IRB_TILED_MFMA_ONE_GRID)
     int tiled_chip_wgs = 768;                // workgroups the partition splits aim for (IRB_TILED_WGS)
     bool pair = false;                       // both channels of every instance share their IR set: paired kernel
     bool nt = false;                         // non-temporal row loads in the fused kernel
@@ -89,7 +84,6 @@ struct irb_fdl {
                                                          // blocks [S][Tmax*B] and IR partitions [P*B] into directly (posted writes over PCIe), so that
                                                          // k_rt_pair's first loads are local instead of PCIe round trips (tools/bar_probe.hip: -2 us per callback)
     unsigned done_seq = 0;
-    bool is_gfx950 = true;                   // the device this handle runs on reports gcnArchName gfx950 (the hand-off forms were measured there)
     bool stepwise = false;                   // IRB_FDL_STEPWISE: a call of n blocks = n one-block steps, ring of P slots
     long long cols_launches = 0, debug_drop_at = 0;   // IRB_DEBUG_DROP_GRANULES=n (tests): the n-th column-sliced launch loses one producer's granules
     unsigned long long n_launches = 0, n_waits = 0, n_copies = 0;   // what the host asked of the runtime since create (irb_fdl_get_counters)
@@ -181,52 +175,17 @@ int dev_alloc(irb_fdl *h, T **p, size_t n)
     default: return fail(IRB_ERR_ARG, "unsupported FFT length %d", N_);    \
     }
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
-
-// Internal knobs (tests, tools, A/B): ONE environment variable, IRB_DEBUG="name=value,name=value".  Not part of the interface;
-// the variables a user may set are listed in INTEGRATION.md.
-int dbg_int(const char *name, int dflt)
-{
-    const char *v = std::getenv("IRB_DEBUG");
-    if (!v) return dflt;
-    const size_t n = std::strlen(name);
-    for (const char *p = v; *p;) {
-        const char *e = std::strchr(p, ',');
-        const size_t len = e ? (size_t) (e - p) : std::strlen(p);
-        if (len > n && !std::strncmp(p, name, n) && p[n] == '=') return std::atoi(p + n + 1);
-        p += len + (e ? 1 : 0);
-    }
-    return dflt;
-}
-
 // One-block steps: which kernel family, and how a stream is spread over workgroups.
-//   fused  (colW = 0, splits = 1)  one workgroup per stream: HBM-sized batches (no hand-off at all)
-//   cols   (colW > 0)              column slices x partition splits, single launch (k_step_cols): few streams
-//                                  (latency) and mid-size batches that one workgroup per stream cannot fill the chip with
-//   split  (colW = 0, splits > 1)  the older partition-split kernels, kept behind IRB_FDL_FORCE_SPLIT
+//   fused  (colW = 0)   one workgroup per stream: HBM-sized batches (no hand-off at all)
+//   cols   (colW > 0)   column slices x partition splits, single launch (k_step_cols): few streams (latency) and mid-size
+//                       batches that one workgroup per stream cannot fill the chip with
+// (rounds 1-4 also carried partition-split kernels with a whole-row hand-off behind IRB_FDL_FORCE_SPLIT; no heuristic chose them)
 void choose_path(irb_fdl *h)
 {
-    const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
+    const int L = h->M / 2;
     h->colW = 0; h->splits = 1; h->cols_handoff = 0;
     if (h->flags & IRB_FDL_FORCE_FUSED) return;
-    if (h->flags & IRB_FDL_FORCE_SPLIT) {
-        // measured optimum of that kernel: 16..64 workgroups per stream with >= 16 partitions per stripe
-        const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
-        h->splits = std::max(2, env_int("IRB_SPLITS", by_work));
-        return;
-    }
     const bool force_cols = (h->flags & IRB_FDL_FORCE_COLS) != 0;
-    if (!force_cols && env_int("IRB_COLS", 1) == 0) {      // A/B switch: the round-1 heuristic (fused from 128 streams, else split)
-        if (h->S >= 128) return;
-        const int by_work = std::min(64, (h->P + stripes * 16 - 1) / (stripes * 16));
-        const int sp = std::min(by_work, std::max(1, 512 / h->S));
-        h->splits = env_int("IRB_SPLITS", sp < 2 ? 1 : sp);
-        return;
-    }
     // Measured on MI355X (profiles/r02_latency_sweep.txt, r02_batch_sweep.txt, r02_step_stamps.txt):
     //  * from 224 streams on, one workgroup per stream (nearly) fills the chip and needs no hand-off: fused kernel
     //    (profiles/r03_batch_sweep.txt: 192 streams cols 1042 / fused 1002 Msamples/s, 256 streams cols 949 / fused 1060);
@@ -235,13 +194,13 @@ void choose_path(irb_fdl *h)
     //  * otherwise column slices x partition splits with <= 256 workgroups (a second workgroup per CU only queues
     //    behind the first on this latency-bound path), two rounds of loads per thread for long IRs (more splits
     //    shorten the loads but every workgroup adds ~13 ns to the stream's ticket counter and a row to the final sum).
-    if (!force_cols && (h->S >= env_int("IRB_FUSED_FROM", 224) || (long) h->P * h->N <= env_int("IRB_FUSED_ROWS", 48) * 512L)) return;
+    if (!force_cols && (h->S >= dbg_int("fused_from", 224) || (long) h->P * h->N <= dbg_int("fused_rows", 48) * 512L)) return;
     int W = 64;
     for (int w : {4, 16, 64}) {
         const int we = std::min(w, L);
         if ((long) h->S * (L / we) <= 64) { W = w; break; }
     }
-    W = env_int("IRB_COLW", W);
+    W = dbg_int("colw", W);
     if (W != 4 && W != 16 && W != 64) W = 64;
     const int we = std::min(W, L), CS = L / we;
     const long base = (long) h->S * CS;
@@ -251,47 +210,35 @@ void choose_path(irb_fdl *h)
     int PS = (h->P + per_two_rounds - 1) / per_two_rounds;
     PS = (int) std::min<long>(PS, std::max<long>(1, 256 / base));
     PS = std::max(1, std::min(PS, 16));
-    PS = std::max(1, env_int("IRB_PSPLITS", PS));
+    PS = std::max(1, dbg_int("psplits", PS));
     h->colW = W;
     h->splits = PS;
-    // hand-off form: tagged granules while the whole grid is certainly resident (<= 256 workgroups: the reducer spins),
-    // else write-through slices + ticket; IRB_COLS_HANDOFF=0|1|2 overrides (1 = release/acquire fences: A/B, tests)
+    // hand-off form: tagged granules (2) while the whole grid is certainly resident (<= 256 workgroups: the reducer spins),
+    // else write-through slices + ticket (0)
     // (measured, profiles/r02_handoff_ab.txt: granules win on narrow slices -- 1 to 8 streams: 5.41 -> 5.15, 7.29 -> 6.39,
-    // 7.18 -> 6.65 us -- and lose from 32 streams on, where one reducer per stream sweeps 2048+ granules)
-    h->cols_handoff = env_int("IRB_COLS_HANDOFF", (base * PS <= 256 && W < 64) ? 2 : 0);
-    if (h->cols_handoff < 0 || h->cols_handoff > 2) h->cols_handoff = 0;
-    // forms 0 and 2 lean on how gfx950 acknowledges write-through stores ("Hand-off form 0"): measured there, not an
-    // architectural guarantee, so any other device gets the release / acquire fences of form 1
-    if (!h->is_gfx950 && !std::getenv("IRB_COLS_HANDOFF")) h->cols_handoff = 1;
+    // 7.18 -> 6.65 us -- and lose from 32 streams on, where one reducer per stream sweeps 2048+ granules).  Both lean on how gfx950
+    // acknowledges write-through stores: measured there; the library is built for that chip only.
+    h->cols_handoff = dbg_int("cols_handoff", (base * PS <= 256 && W < 64) ? 2 : 0) == 2 ? 2 : 0;
 }
 
 constexpr int kCkMax = 1024;                  // output chunks of a staged one-shot piece (irb_fdl::d_ck / h_ck)
-constexpr int kTT = 8;                        // outputs per time tile (k_cmac_tiled)
-constexpr int kPadP = irb::kTilePeriod;       // H rows per set: P rounded up to this (a multiple of kTT); the extra rows stay zero
+constexpr int kRingSpare = 8;                 // ring slots beyond P history + the call's blocks (a tile's overhang)
+constexpr int kPadP = irb::kTilePeriod;       // H rows per set: P rounded up to this; the extra rows stay zero
 
 // outputs per time tile for a call of T blocks: 16, or 8 when the call has no more than 8 blocks (a 16-output tile would multiply
 // eight outputs nobody keeps: on HBM-sized batches of 8-block calls the MAC is then as expensive as the row traffic)
-int tile_outputs(const irb_fdl *h, int T)
-{
-    if (h->tiled_kernel == 0) return kTT;
-    return (T <= 8 && env_int("IRB_TILED_TT8", 1)) ? 8 : h->tileTT;
-}
+int tile_outputs(const irb_fdl *, int T) { return T <= 8 ? 8 : 16; }
 
-// partition splits for a call of T blocks: enough workgroups to fill the chip, but every stripe keeps
-// at least two full window steps of partitions
+// partition splits for a call of T blocks: as many as still fit the resident slots in ONE round (every split adds a partial spectrum
+// per output that is written, flushed and read back), every worker at least one ring period of partitions
 int tiled_splits(const irb_fdl *h, int T)
 {
     const int L = h->M / 2, LW = std::min(L, irb::kThreads), stripes = irb::kThreads / LW;
     const int tt = tile_outputs(h, T);
     const int ntiles = (T + tt - 1) / tt;
-    const int by_work = h->tiled_kernel == 0 ? std::max(1, (h->Ppad / kTT) / (stripes * 2))
-                                             : std::max(1, (h->Ppad / kPadP) / stripes);     // every worker at least one ring period
+    const int by_work = std::max(1, (h->Ppad / kPadP) / stripes);
     const long wgs = (long) h->S * ntiles;
-    // round-2 kernel: at least tiled_chip_wgs workgroups; packed-FMA kernels: as many splits as still fit the resident
-    // slots in ONE round (every split adds a partial spectrum per output that is written, flushed and read back)
-    const int by_chip = h->tiled_kernel == 0 ? (int) std::max<long>(1, (h->tiled_chip_wgs + wgs - 1) / wgs)
-                                             : (int) std::max<long>(1, h->tiled_chip_wgs / wgs);
-    if (h->tiled_splits_override > 0) return std::max(1, std::min(by_work, h->tiled_splits_override));   // IRB_TILED_SPLITS
+    const int by_chip = (int) std::max<long>(1, h->tiled_chip_wgs / wgs);
     return std::max(1, std::min(by_work, by_chip));
 }
 
@@ -327,17 +274,17 @@ MfmaPlan mfma_plan(const irb_fdl *h, int T)
     const long units = (long) h->S * (h->M / irb::kMfmaBins);                                // workgroups per tile at one split
     const int by_work = std::max(1, irb::mfma_chunks(h->P) / h->mfma_min_chunks);           // every split keeps a few chunks
     const int target = h->mfma_wgs;
-    const long slots = (long) target * h->mfma_res;                                          // workgroups resident at once
+    const long slots = target;                                                               // workgroups resident at once: one per CU (two start late and multiply slower, profiles/r04_mfma_stamps.txt)
     auto splits_for = [&](long wgs) { return (int) std::max<long>(1, std::min<long>(by_work, slots / std::max<long>(1, wgs))); };
     const long per_round = target / units;                                                   // tiles that give every CU one workgroup
     auto run = [&](int first, int ntiles) {                                                  // tiles [first, first + ntiles)
         if (ntiles <= 0) return;
         const int full = per_round > 0 ? (int) (ntiles / per_round * per_round) : ntiles;
-        if (full == 0 || !h->mfma_two_launch) {
+        if (full == 0) {
             p.l[p.n++] = {first, ntiles, ntiles * units <= target ? splits_for(ntiles * units) : 1};
             return;
         }
-        p.l[p.n++] = {first, full, std::min(by_work, h->mfma_res)};
+        p.l[p.n++] = {first, full, 1};
         // (the remainder's workgroups are few and short: down to three chunks per split)
         if (ntiles > full) p.l[p.n++] = {first + full, ntiles - full,
                                           (int) std::max<long>(1, std::min<long>(std::max(1, irb::mfma_chunks(h->P) / 3), slots / std::max<long>(1, (ntiles - full) * units)))};
@@ -360,7 +307,7 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.in_len = a.out_len = (long) 1 << 62;
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.ck_cnt = nullptr; a.ck_flag = nullptr; a.ck_blocks = 1; a.ck_seq = 0;
-    a.pk_flag = nullptr; a.pk_blocks = 16; a.pk_seq = 0;
+    a.pk_flag = nullptr; a.pk_blocks = 16; a.pk_seq = 0; a.dbg_sums = nullptr;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -379,7 +326,6 @@ int launch_cols(irb_fdl *h, irb::StepArgs a)
     h->n_launches++;
     a.debug_drop = (++h->cols_launches == h->debug_drop_at) ? 1 : 0;
     if (h->cols_handoff == 2) { LAUNCH_COLS_W(2) }
-    else if (h->cols_handoff == 1) { LAUNCH_COLS_W(1) }
     else { LAUNCH_COLS_W(0) }
     HIP_TRY(hipGetLastError());
     return IRB_OK;
@@ -403,25 +349,17 @@ int check_status(irb_fdl *h)
 int launch_step(irb_fdl *h, const irb::StepArgs &a)
 {
     if (h->colW > 0) return launch_cols(h, a);
-    h->n_launches += (h->splits > 1 && (h->flags & IRB_FDL_SPLIT_3LAUNCH)) ? 3 : 1;
-    if (h->splits <= 1) {
-        // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
-        // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
-        if (h->pair && h->N <= 2048) {
-            if (h->nt) { FOR_N(h->N, irb::k_step_fused_pair<NN, true><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-            else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        }
-        else if (h->fused_u == 4 && h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 4, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        else if (h->fused_u == 4)          { FOR_N(h->N, irb::k_step_fused<NN, 4, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-        else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
-    } else if (!(h->flags & IRB_FDL_SPLIT_3LAUNCH)) {
-        FOR_N(h->N, irb::k_step_split<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a, h->d_tickets));
-    } else {
-        FOR_N(h->N, irb::k_push_fft<NN><<<dim3((h->S + irb::FftGeom<NN>::NF - 1) / irb::FftGeom<NN>::NF), dim3(irb::kWave * irb::FftGeom<NN>::NF), 0, h->stream>>>(a, h->S));
-        FOR_N(h->N, irb::k_cmac_partial<NN><<<dim3(h->S * h->splits), dim3(irb::kThreads), 0, h->stream>>>(a));
-        FOR_N(h->N, irb::k_reduce_ifft_ola<NN><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a));
+    h->n_launches++;
+    // rows streamed once per step from a working set beyond the 256 MiB Infinity Cache: non-temporal
+    // loads (+10 % HBM rate, profiles/r01_fused_variants.txt); cache-resident sets keep the default policy
+    if (h->pair && h->N <= 2048) {
+        if (h->nt) { FOR_N(h->N, irb::k_step_fused_pair<NN, true><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+        else       { FOR_N(h->N, irb::k_step_fused_pair<NN, false><<<dim3(h->S / 2), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     }
+    else if (h->fused_u == 4 && h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 4, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    else if (h->fused_u == 4)          { FOR_N(h->N, irb::k_step_fused<NN, 4, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    else if (h->nt) { FOR_N(h->N, irb::k_step_fused<NN, 2, true><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
+    else       { FOR_N(h->N, irb::k_step_fused<NN, 2, false><<<dim3(h->S), dim3(irb::kThreads), 0, h->stream>>>(a)); }
     HIP_TRY(hipGetLastError());
     return IRB_OK;
 }
@@ -463,7 +401,7 @@ int tiled_begin(irb_fdl *h, irb::StepArgs a, int T, TiledCall *c)
         }
     }
     else if (c->one_bin) a.nq = a.splits * stripes1;
-    else if (h->tiled_kernel != 0) a.nq = a.splits;          // k_cmac_tiled_pk adds its stripes before it stores
+    else a.nq = a.splits;                                    // k_cmac_tiled_pk adds its stripes before it stores
     if (!c->mfma) {
         if ((size_t) h->S * T * a.nq > h->part_rows) return fail(IRB_ERR_STATE, "partial workspace too small (internal)");
         for (int r = 0; r < 3; r++) a.reg_t0[r] = r == 0 ? 0 : T;                            // one region: part[s][t][nq][M]
@@ -501,8 +439,7 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count, hipStream_t
     return IRB_OK;
 }
 
-// (matrix-core calls: launches [first_launch, first_launch + n_launches) of the plan; every other kernel is one launch)
-int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launches = 2)
+int tiled_mac(irb_fdl *h, const TiledCall &c)
 {
     irb::StepArgs a = c.a;
     const dim3 mac_grid(h->S * c.ntiles * a.splits), mac_block(irb::kThreads);
@@ -514,8 +451,8 @@ int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launch
         float2 *const part0 = a.part;
         h->n_launches--;
         auto wgs = [&](const MfmaLaunch &l) { return h->S * l.tile_count * l.splits * groups; };
-        if (h->mfma_one_grid && first_launch == 0 && n_launches >= 2 && c.plan.n == 2) {
-            // both launches of the plan in ONE grid: the second's workgroups (few, short) come last in dispatch order and run on
+        if (c.plan.n == 2) {
+            // both regions of the plan in ONE grid: the second's workgroups (few, short) come last in dispatch order and run on
             // the CUs the first round frees -- one launch's fixed cost instead of two
             const MfmaLaunch &l0 = c.plan.l[0], &l1 = c.plan.l[1];
             h->n_launches++;
@@ -526,21 +463,15 @@ int tiled_mac(irb_fdl *h, const TiledCall &c, int first_launch = 0, int n_launch
             a.mf2_t_base = a.reg_t0[1]; a.mf2_part_T = a.reg_t0[2] - a.reg_t0[1]; a.mf2_part_off = (long) a.reg_off[1] - (long) a.reg_off[0];
             FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l0) + wgs(l1)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
         } else {
-            for (int i = first_launch; i < std::min(c.plan.n, first_launch + n_launches); i++) {
-                const MfmaLaunch &l = c.plan.l[i];
-                h->n_launches++;
-                a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
-                a.t_base = a.reg_t0[i]; a.part_T = a.reg_t0[i + 1] - a.reg_t0[i]; a.part = part0 + a.reg_off[i];
-                a.mf_wgs0 = 0;
-                FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
-            }
+            const MfmaLaunch &l = c.plan.l[0];
+            h->n_launches++;
+            a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
+            a.t_base = a.reg_t0[0]; a.part_T = a.reg_t0[1] - a.reg_t0[0]; a.part = part0 + a.reg_off[0];
+            a.mf_wgs0 = 0;
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
         }
     }
     else if (c.one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    else if (h->tiled_kernel == 0) {
-        if (nt1) { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-        else     { FOR_N(h->N, irb::k_cmac_tiled<NN, kTT, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
-    }
     else if (c.tt == 8 && nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (c.tt == 8)        { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, false><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 16, 8, 2, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
@@ -570,7 +501,7 @@ void tiled_end(irb_fdl *h, const TiledCall &c)
 // calls of at most 8 blocks on batches whose streams get one workgroup each: push, multiply and inverse in ONE launch (k_tile8_fused)
 bool use_tile8_fused(const irb_fdl *h, int T)
 {
-    return h->tile8_fused && h->tiled_kernel != 0 && h->N >= 256 && h->N <= 1024 && tile_outputs(h, T) == 8 && tiled_splits(h, T) == 1 && !use_mfma(h, T);
+    return h->tile8_fused && h->N >= 256 && h->N <= 1024 && tile_outputs(h, T) == 8 && tiled_splits(h, T) == 1 && !use_mfma(h, T);
 }
 
 int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
@@ -644,7 +575,7 @@ bool device_quiet(int dev) { return dev >= 0 && dev < kMaxDevices && g_quiet[dev
 void quiet_begin(int dev)
 {
     if (dev < 0 || dev >= kMaxDevices) return;
-    static const bool off = env_int("IRB_DEVICE_QUIET", 1) == 0;        // diagnostic: what the library did before round 4 (profiles/r04_resident_vs_process.txt)
+    static const bool off = dbg_int("device_quiet", 1) == 0;        // diagnostic: what the library did before round 4 (profiles/r04_resident_vs_process.txt)
     if (off) { g_quiet_disabled.store(true); return; }
     g_quiet[dev].fetch_add(1, std::memory_order_seq_cst);
     std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -988,9 +919,15 @@ struct OfflineEngineGuard {
     Crew crew;
     irb_convolve_profile prof;
     bool have_prof = false;
+    // diagnostic (IRB_DEBUG=input_checksums=1): per-block checksums of the samples the forward-FFT kernels read in the last call, [C][steps]
+    unsigned *d_sums = nullptr;
+    size_t d_sums_cap = 0;
+    std::vector<unsigned> sums;
+    int sums_streams = 0, sums_blocks = 0;
     void release()
     {
         crew.stop();
+        if (d_sums) { (void) hipFree(d_sums); d_sums = nullptr; d_sums_cap = 0; }
         if (!eng) return;
         DeviceQuiet quiet(eng->device);                // frees wait for every stream of the device: resident servers step aside
         (void) hipSetDevice(eng->device);
@@ -1068,44 +1005,30 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
     h->Ppad = (h->P + kPadP - 1) / kPadP * kPadP;
     h->Tmax = cfg->max_blocks_per_call;
     h->flags = cfg->flags;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->is_gfx950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
-    }
     h->stepwise = (h->flags & IRB_FDL_STEPWISE) != 0 || h->Tmax == 1;
-    h->R = h->stepwise ? h->P : h->Ppad + h->Tmax + kTT;     // tiled path: P past blocks + the call's blocks + tile overhang
+    h->R = h->stepwise ? h->P : h->Ppad + h->Tmax + kRingSpare;     // tiled path: P past blocks + the call's blocks + tile overhang
     choose_path(h);
     h->nt = (size_t) h->S * h->M * sizeof(float2) * (size_t) (h->Ppad + h->R) > ((size_t) 256 << 20);
-    if (const char *v = std::getenv("IRB_SPLIT_3LAUNCH")) { if (std::atoi(v)) h->flags |= IRB_FDL_SPLIT_3LAUNCH; }
-    if (const char *v = std::getenv("IRB_FUSED_NT")) h->nt = std::atoi(v) != 0;     // tuning override
+    { bool set = false; const int v = dbg_int("fused_nt", 0, &set); if (set) h->nt = v != 0; }     // tuning override
     h->tiled1 = h->nt;
-    if (const char *v = std::getenv("IRB_TILED1")) h->tiled1 = std::atoi(v) != 0;
-    if (const char *v = std::getenv("IRB_TILED_SPLITS")) h->tiled_splits_override = std::atoi(v);
-    h->debug_drop_at = env_int("IRB_DEBUG_DROP_GRANULES", 0);
+    { bool set = false; const int v = dbg_int("tiled1", 0, &set); if (set) h->tiled1 = v != 0; }
+    h->debug_drop_at = dbg_int("drop_granules", 0);
     // at most one workgroup per CU (no second workgroup to overlap its loads with): twice the rows in flight per thread
     // (profiles/r03_batch_sweep.txt: 256 streams 945 -> 1060 Msamples/s; as soon as some CUs hold two workgroups U = 2 is faster)
-    h->fused_u = env_int("IRB_FUSED_U", (h->colW == 0 && h->splits <= 1 && h->S <= 256) ? 4 : 2);
+    h->fused_u = dbg_int("fused_u", (h->colW == 0 && h->S <= 256) ? 4 : 2);
     if (h->fused_u != 4) h->fused_u = 2;
-    h->tiled_kernel = env_int("IRB_TILED_KERNEL", 1);
-    if (h->tiled_kernel < 0 || h->tiled_kernel > 1) h->tiled_kernel = 1;
-    h->tileTT = h->tiled_kernel == 0 ? kTT : 16;
-    h->tile8_fused = env_int("IRB_TILED_FUSED8", 1) != 0;
-    h->mfma_min_T = std::max(0, env_int("IRB_TILED_MFMA_MIN_T", 256));
-    h->mfma_wgs = std::max(1, env_int("IRB_TILED_MFMA_WGS", 256));
-    h->mfma_min_chunks = std::max(1, env_int("IRB_TILED_MFMA_MIN_CHUNKS", 6));
-    h->mfma_two_launch = env_int("IRB_TILED_MFMA_TWO_LAUNCH", 1) != 0;
-    h->mfma_one_grid = env_int("IRB_TILED_MFMA_ONE_GRID", 1) != 0;
-    h->mfma_res = std::max(1, std::min(2, env_int("IRB_TILED_MFMA_RES", 1)));       // measured (profiles/r04_mfma_stamps.txt): two per CU start late and multiply slower
-    // gfx950 only: the instruction timings and the DPP / buffer-load forms the kernel is written in are that chip's
-    h->mfma_capable = h->is_gfx950 && !h->stepwise && h->mfma_min_T > 0 && h->Tmax >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
+    h->tile8_fused = dbg_int("tiled_fused8", 1) != 0;
+    h->mfma_min_T = std::max(0, dbg_int("mfma_min_t", 256));
+    h->mfma_wgs = std::max(1, dbg_int("mfma_wgs", 256));
+    h->mfma_min_chunks = std::max(1, dbg_int("mfma_min_chunks", 6));
+    // gfx950 only (what the library is built for): the instruction timings and the DPP / buffer-load forms the kernel is written in are that chip's
+    h->mfma_capable = !h->stepwise && h->mfma_min_T > 0 && h->Tmax >= h->mfma_min_T && h->M % irb::kMfmaBins == 0;
     if (h->mfma_capable) {
         h->xt_hist = irb::mfma_hist(h->P);
         h->xt_len = h->xt_hist + (h->Tmax + irb::kMfmaTile - 1) / irb::kMfmaTile * irb::kMfmaTile;
         h->ht_len = irb::mfma_taps(h->P);
     }
-    // resident workgroups of the MAC kernel: 256 CUs x waves per SIMD its registers allow (2 / 2 / 3 / 4); round 2: 768 as a floor
-    const int slots[2] = {768, 512};
-    h->tiled_chip_wgs = std::max(1, env_int("IRB_TILED_WGS", slots[h->tiled_kernel]));
+    h->tiled_chip_wgs = 512;     // resident workgroups of k_cmac_tiled_pk: 256 CUs x the two per CU its registers allow
 
     int rc = IRB_OK;
     auto guard = [&](int r) { if (r != IRB_OK && rc == IRB_OK) rc = r; return r == IRB_OK; };
@@ -1179,7 +1102,7 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             std::memset(h->h_ck, 0, sizeof(unsigned) * 16 * 2 * kCkMax);
             std::memset(h->h_pk, 0, sizeof(unsigned) * 16 * 2 * kCkMax);
         }
-        if (h->host_io && h->stepwise && env_int("IRB_RT_BAR", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
+        if (h->host_io && h->stepwise && dbg_int("rt_bar", 1)) {     // (the real-time callback's staging; irb_convolve_periodic's engine is host_io too but never stepwise)
             int large_bar = 0;
             if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && large_bar) {
                 const size_t nin = ((size_t) h->S * h->Tmax * h->B + 15) / 16 * 16, nir = ((size_t) h->P * h->B + 15) / 16 * 16;
@@ -1248,13 +1171,11 @@ const char *irb_fdl_mac_kernel_name(const irb_fdl *h, int n_blocks)
     const int T = h->stepwise ? 1 : std::min(n_blocks, h->Tmax);
     if (T == 1) {
         if (h->colW > 0) return "k_step_cols";
-        if (h->splits > 1) return (h->flags & IRB_FDL_SPLIT_3LAUNCH) ? "k_cmac_partial" : "k_step_split";
         return (h->pair && h->N <= 2048) ? "k_step_fused_pair" : "k_step_fused";
     }
     if (use_tile8_fused(h, T)) return "k_tile8_fused";
     if (use_mfma(h, T)) return "k_cmac_mfma";
     if (h->tiled1 && T >= 16 && h->N >= 128 && h->N <= 2048) return "k_cmac_tiled1<16>";
-    if (h->tiled_kernel == 0) return "k_cmac_tiled<8>";
     return tile_outputs(h, T) == 8 ? "k_cmac_tiled_pk<8,4>" : "k_cmac_tiled_pk<16,8>";
 }
 
@@ -1820,9 +1741,10 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     bool direct = false, ir_direct = false;
     float *d_audio[2] = {nullptr, nullptr}, *d_res[2] = {nullptr, nullptr};
     const float *d_irp[2] = {nullptr, nullptr};
-    if (mode != DirectMode::kNever && steps >= 2) {
+    // resolve the caller's buffers; register == true only AFTER the engine exists (see below)
+    auto resolve_direct = [&](bool register_pageable) {
         const double t_reg = now_ms();
-        if (mode == DirectMode::kRegister) {
+        if (register_pageable) {
             // (registering and unregistering host memory are device-wide operations for the runtime: with a resident real-time server
             // alive on the device the call waited until that server's callbacks stopped, so the registering form sits in a quiet section)
             quiet.reset(new DeviceQuiet(device));
@@ -1848,12 +1770,13 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             direct = d_audio[c] && d_res[c];
         }
         for (int c = 0; c < ir_ch && direct && ir_direct; c++) {
-            d_irp[c] = (mode == DirectMode::kRegister ? ranges : ir_ranges).dev(ir[c]);
+            d_irp[c] = (register_pageable ? ranges : ir_ranges).dev(ir[c]);
             if (!d_irp[c]) ir_direct = false;
         }
-        if (!direct) { ranges.release(); ir_ranges.release(); quiet.reset(); }   // not HIP host memory (or a registration refused): the staged form
+        if (!direct) { ranges.release(); ir_ranges.release(); quiet.reset(); ir_direct = false; }   // not HIP host memory (or a registration refused): the staged form
         else { prof.register_ms = now_ms() - t_reg; prof.registered_ranges = ranges.n_registered; }
-    }
+    };
+    if (mode == DirectMode::kPinnedOnly && steps >= 2) resolve_direct(false);     // (look-ups only: nothing of the process's memory changes its status)
     auto release_ranges = [&]() { ranges.release(); ir_ranges.release(); quiet.reset(); direct = ir_direct = false; };
 
     // ---- how the signal is cut into pieces.  One piece wherever it fits: a piece costs the multiply a whole round of workgroups and the
@@ -1912,6 +1835,15 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         return code;
     };
     int rc = IRB_OK;
+    // The opt-in registering form, only NOW: a registration covers whole pages, so small heap objects next to the caller's buffers become
+    // "registered host memory" too for as long as it lasts -- the runtime refused the engine's own set-up copies out of such a neighbour
+    // ("invalid argument": tools/fuzz_paths.py, round 5) when the registration came first.  From here to the release only kernels
+    // are launched.  (The signal was cut as for the staged form, so a refused registration needs no second plan.)
+    if (mode == DirectMode::kRegister && steps >= 2) {
+        bool one_block_piece = false;
+        for (int T : piece_T) one_block_piece |= T == 1;
+        if (!one_block_piece) resolve_direct(true);
+    }
     const bool device_times = g_offline_profile_events;
     if (device_times) {
         const size_t want = (size_t) 5 * std::min(n_pieces, kOfflineTimedPieces);
@@ -2037,6 +1969,19 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         return fail(e != hipSuccess ? IRB_ERR_HIP : IRB_ERR_STATE, "one-shot pipeline: an output chunk never arrived (%s)", e != hipSuccess ? hipGetErrorString(e) : "no device error reported");
     };
     int mac_launches = 1, nin_total = 0, nout_total = 0, last_ck = 0;
+    const bool want_sums = dbg_int("input_checksums", 0) != 0;
+    g.sums.clear(); g.sums_streams = g.sums_blocks = 0;
+    if (want_sums) {
+        const size_t need = (size_t) audio_ch * (size_t) steps;
+        if (g.d_sums_cap < need) {
+            if (g.d_sums) (void) hipFree(g.d_sums);
+            g.d_sums = nullptr; g.d_sums_cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&g.d_sums), sizeof(unsigned) * need) != hipSuccess) return bail(fail(IRB_ERR_HIP, "checksum buffer"));
+            g.d_sums_cap = need;
+        }
+        g.sums.assign(need, 0u);
+    }
+    std::vector<unsigned> piece_sums;
     long p0 = 0;
     for (int k = 0; k < n_pieces && rc == IRB_OK; p0 += piece_T[(size_t) k], k++) {
         const int T = piece_T[(size_t) k];
@@ -2073,6 +2018,17 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
             // the next piece's forward FFTs wait for "multiply k done": nothing is pending, the event says so
             if (hipEventRecord(h->ev_pipe[2 + (k & 1)], h->stream) != hipSuccess) { rc = fail(IRB_ERR_HIP, "hipEventRecord failed"); break; }
             continue;
+        }
+        if (want_sums) {
+            // (diagnostic: a piece's sums are fetched before the next piece reuses the buffer -- these calls are not the fast ones)
+            if (k >= 1) {
+                (void) hipStreamSynchronize(s_in);
+                piece_sums.resize((size_t) audio_ch * piece_T[(size_t) k - 1]);
+                if (hipMemcpy(piece_sums.data(), g.d_sums, sizeof(unsigned) * piece_sums.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                    for (int c = 0; c < audio_ch; c++)
+                        for (int j = 0; j < piece_T[(size_t) k - 1]; j++) g.sums[(size_t) c * steps + (size_t) (p0 - piece_T[(size_t) k - 1] + j)] = piece_sums[(size_t) c * piece_T[(size_t) k - 1] + j];
+            }
+            a.dbg_sums = g.d_sums;
         }
         TiledCall call;
         rc = tiled_begin(h, a, T, &call);
@@ -2144,6 +2100,15 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
         prof.stall_ms = now_ms() - t_wait;
     }
     if (rc != IRB_OK) return bail(rc);
+    if (want_sums && piece_T.back() > 1) {
+        const int Tl = piece_T.back();
+        (void) hipStreamSynchronize(s_in);
+        piece_sums.resize((size_t) audio_ch * Tl);
+        if (hipMemcpy(piece_sums.data(), g.d_sums, sizeof(unsigned) * piece_sums.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int c = 0; c < audio_ch; c++)
+                for (int j = 0; j < Tl; j++) g.sums[(size_t) c * steps + (size_t) (steps - Tl + j)] = piece_sums[(size_t) c * Tl + j];
+        g.sums_streams = audio_ch; g.sums_blocks = (int) steps;
+    }
     if (sc) sc->finished.store(1);
     rc = check_status(h);
     if (rc != IRB_OK) return bail(rc);
@@ -2202,6 +2167,19 @@ int irb_convolve_profile_events(int on)
     const int was = g_offline_profile_events ? 1 : 0;
     g_offline_profile_events = on != 0;
     return was;
+}
+
+// diagnostic, not part of the interface (tools/fuzz_paths.py): the calling thread's last irb_convolve_periodic call under
+// IRB_DEBUG=input_checksums=1 -- per stream and block the sum of the bit patterns of the samples the forward-FFT kernel read
+int irb_debug_input_checksums_(unsigned *dst, int capacity, int *streams, int *blocks)
+{
+    if (!dst || !streams || !blocks) return fail(IRB_ERR_ARG, "null argument");
+    *streams = g_offline.sums_streams; *blocks = g_offline.sums_blocks;
+    const size_t n = (size_t) g_offline.sums_streams * (size_t) g_offline.sums_blocks;
+    if (n == 0 || g_offline.sums.size() < n) return fail(IRB_ERR_STATE, "no checksums: the last call did not run under IRB_DEBUG=input_checksums=1");
+    if ((size_t) capacity < n) return fail(IRB_ERR_ARG, "buffer too small for %zu checksums", n);
+    std::memcpy(dst, g_offline.sums.data(), sizeof(unsigned) * n);
+    return IRB_OK;
 }
 
 int irb_convolve_last_profile(irb_convolve_profile *out)

@@ -19,9 +19,6 @@
 
 #include "fft_wave.hpp"
 
-#ifndef IRB_TILED_SCHED_BARRIER
-#define IRB_TILED_SCHED_BARRIER 1
-#endif
 
 namespace irb {
 
@@ -99,6 +96,10 @@ struct StepArgs {
     const unsigned *pk_flag;
     int           pk_blocks;
     unsigned      pk_seq;
+    // diagnostic (IRB_DEBUG=input_checksums=1, tools/fuzz_paths.py): the batched forward-FFT kernels leave the sum of the bit patterns of
+    // every block's samples AS THEY READ THEM at dbg_sums[s * T + j] -- what a wrong result is compared with first (did the device see
+    // the bytes the host sees?)
+    unsigned     *dbg_sums;
 };
 
 #ifdef IRB_STAMPS
@@ -119,6 +120,18 @@ __device__ __forceinline__ void stamp_(unsigned long long *buf, int i)
     }
 }
 #endif
+
+// diagnostic (StepArgs::dbg_sums): the sum of the bit patterns of the zero-padded block a wave has just put into z (every lane adds the
+// floats it stored itself)
+template <int N>
+__device__ __forceinline__ void wave_block_checksum(const float2 *z, int lane, unsigned *dst)
+{
+    const unsigned *zu = reinterpret_cast<const unsigned *>(z);
+    unsigned acc = 0;
+    for (int n = lane; n < N; n += kWave) acc += zu[n];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if (lane == 0) *dst = acc;
+}
 
 // Overlap-add (reference fp/convolution.cpp:209-213) by one wave: y = N real samples, unscaled, in LDS.
 __device__ __forceinline__ void wave_overlap_add(const float *y, float scale, int B, float *__restrict__ ovl,
@@ -516,216 +529,13 @@ __global__ __launch_bounds__(kThreads) void k_step_fused_pair(StepArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split path, for few streams with long IRs (one workgroup per stream cannot fill the chip):
-//   k_push_fft        grid = S            new block -> FFT -> ring slot `head`
-//   k_cmac_partial    grid = S*splits     partial sums over a contiguous partition range
-//   k_reduce_ifft_ola grid = S            sum of the partials -> IFFT -> overlap-add
-// ---------------------------------------------------------------------------------------------
-// one wave per stream; NF streams per workgroup
-template <int N>
-__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft(StepArgs a, int S)
-{
-    constexpr int M = N / 2, NF = FftGeom<N>::NF;
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[NF][M];
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int s = blockIdx.x * NF + wave;
-    TwiddleStage<N, kWave * NF> tws;
-    tws.load(a.tw);
-    if (s < S) wave_load_block<M>(a.in + (size_t) s * a.in_stride, a.B, l_buf[wave], lane);
-    tws.store(l_tw);
-    __syncthreads();
-    if (s >= S) return;
-    wave_fft<M, false>(l_buf[wave], l_tw, lane);
-    float2 *dst = a.X + ((size_t) s * a.R + a.head) * M;
-    wave_split_forward<M>(l_buf[wave], l_tw, lane, [&](int b, float2 v) { dst[b] = v; });
-}
-
-template <int N>
-__global__ __launch_bounds__(kThreads) void k_cmac_partial(StepArgs a)
-{
-    using G = MacGeom<N>;
-    constexpr int M = N / 2;
-    __shared__ float2 part[G::STRIPES * M];
-    __shared__ float2 Y[M];
-    const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
-    const int2 si = a.stream_info[s];
-    const int set = si.x, np = si.y;
-    const int kb = (int) ((long) np * j / a.splits), ke = (int) ((long) np * (j + 1) / a.splits);
-    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
-    const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
-    float4 acc[G::CPT];
-#pragma unroll
-    for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 dc = make_float2(0.f, 0.f);
-    mac_range<N, 4>(H4, X4, kb, ke, a.head, a.R, acc, dc);
-    reduce_stripes<N>(acc, dc, part, Y);
-    float2 *dst = a.part + ((size_t) s * a.splits + j) * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) dst[b] = Y[b];
-}
-
-// sum of `nrows` partial spectra (rows of M float2, row r at src + r*M) by the whole workgroup:
-// stripes take interleaved rows with 4 loads in flight, then combine through LDS.  Result in Y (LDS).
-template <int N>
-__device__ __forceinline__ void sum_partials(const float2 *__restrict__ src, int nrows, float2 *part, float2 *Y)
-{
-    using G = MacGeom<N>;
-    const int col = threadIdx.x % G::LW, stripe = threadIdx.x / G::LW;
-    const float4 *src4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll 1
-    for (int c = 0; c < G::CPT; c++) {
-        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
-        int r = stripe;
-        for (; r + 3 * G::STRIPES < nrows; r += 4 * G::STRIPES) {
-            const float4 v0 = src4[(size_t) r * G::L + col + c * G::LW];
-            const float4 v1 = src4[(size_t) (r + G::STRIPES) * G::L + col + c * G::LW];
-            const float4 v2 = src4[(size_t) (r + 2 * G::STRIPES) * G::L + col + c * G::LW];
-            const float4 v3 = src4[(size_t) (r + 3 * G::STRIPES) * G::L + col + c * G::LW];
-            t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
-            t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
-            t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
-            t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
-        }
-        for (; r < nrows; r += G::STRIPES) {
-            const float4 v0 = src4[(size_t) r * G::L + col + c * G::LW];
-            t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
-        }
-        const float4 t = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y),
-                                     (t0.z + t1.z) + (t2.z + t3.z), (t0.w + t1.w) + (t2.w + t3.w));
-        reinterpret_cast<float4 *>(part)[stripe * G::L + col + c * G::LW] = t;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < G::M; b += kThreads) {
-        float2 v = part[b];
-#pragma unroll
-        for (int t = 1; t < G::STRIPES; t++) v = cadd(v, part[t * G::M + b]);
-        Y[b] = v;
-    }
-    __syncthreads();
-}
-
-template <int N>
-__global__ __launch_bounds__(kThreads) void k_reduce_ifft_ola(StepArgs a)
-{
-    using G = MacGeom<N>;
-    constexpr int M = N / 2;
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[M];
-    __shared__ float2 l_part[G::STRIPES * M];
-    const int s = blockIdx.x;
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    stage_twiddles<N>(a.tw, l_tw);
-    sum_partials<N>(a.part + (size_t) s * a.splits * M, a.splits, l_part, l_buf);   // ends with a barrier (covers l_tw)
-    if (wave == 0) {
-        wave_split_inverse<M>(l_buf, l_tw, lane);
-        wave_fft<M, true>(l_buf, l_tw, lane);
-        wave_overlap_add(reinterpret_cast<const float *>(l_buf), 1.0f / (float) N, a.B,
-                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_step_split: the split path in ONE launch.  grid = S*splits.  Workgroup (s, j) sums its partition
-// range into a slab; split 0 also transforms the new block (only its range contains partition 0).
-// The last workgroup of a stream to arrive (ticket counter, no waiting anywhere) adds the slabs and does
-// the inverse FFT + overlap-add.  Hand-off follows the counter form of the agent-scope release/acquire
-// protocol (cdna_hip_programming.md Guideline 16): plain slab stores, every wave drains vmcnt, workgroup
-// barrier, one lane: release fence + drained wait + relaxed agent-scope ticket; the last arriver: acquire
-// fence + wait + barrier, then plain loads.  The counter is zeroed at create and re-zeroed by the last
-// arriver (the next launch is stream-ordered behind this one).
-// ---------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(kThreads) void k_step_split(StepArgs a, unsigned *__restrict__ tickets)
-{
-    using G = MacGeom<N>;
-    constexpr int M = N / 2;
-    __shared__ Lds<N> lds;
-    __shared__ unsigned l_ticket;
-    const int j = blockIdx.x % a.splits, s = blockIdx.x / a.splits;
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int2 si = a.stream_info[s];
-    const int set = si.x, np = si.y;
-    // Partition 0 pairs with the block that split 0 transforms in THIS launch, so it always belongs to split 0
-    // (through LDS); only the older partitions [1, np) are divided over the splits.  np comes from the IR in use,
-    // splits from the engine's capacity: np < splits just leaves some splits with an empty range.
-    const int nold = np > 0 ? np - 1 : 0;
-    const int kb = 1 + (int) ((long) nold * j / a.splits), ke = 1 + (int) ((long) nold * (j + 1) / a.splits);
-    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
-    float2 *Xs = a.X + (size_t) s * a.R * M;
-    const float4 *X4 = reinterpret_cast<const float4 *>(Xs);
-
-    stage_twiddles<N>(a.tw, lds.tw);
-    if (j == 0 && wave == 0) wave_load_block<M>(a.in + (size_t) s * a.in_stride, a.B, lds.buf, lane);
-
-    float4 acc[G::CPT];
-#pragma unroll
-    for (int c = 0; c < G::CPT; c++) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 dc = make_float2(0.f, 0.f);
-    mac_range<N, 4>(H4, X4, kb, ke, a.head, a.R, acc, dc);
-    __syncthreads();                                   // twiddles (and split 0's block) are in LDS
-
-    if (j == 0) {
-        if (wave == 0) {
-            wave_fft<M, false>(lds.buf, lds.tw, lane);
-            float2 *ring = Xs + (size_t) a.head * M;
-            wave_split_forward<M>(lds.buf, lds.tw, lane, [&](int b, float2 v) { lds.scratch[b] = v; ring[b] = v; });
-        }
-        __syncthreads();
-        if (np > 0 && threadIdx.x < G::LW) {           // partition 0 with the new block's spectrum
-            const int col = threadIdx.x;
-#pragma unroll
-            for (int c = 0; c < G::CPT; c++) {
-                const float4 h = H4[col + c * G::LW];
-                const float4 x = reinterpret_cast<const float4 *>(lds.scratch)[col + c * G::LW];
-                if (c == 0) { dc.x += x.x * h.x; dc.y += x.y * h.y; }
-                acc[c].x += x.x * h.x - x.y * h.y;
-                acc[c].y += x.x * h.y + x.y * h.x;
-                acc[c].z += x.z * h.z - x.w * h.w;
-                acc[c].w += x.z * h.w + x.w * h.z;
-            }
-        }
-        __syncthreads();
-    }
-
-    reduce_stripes<N>(acc, dc, lds.scratch, lds.buf);
-    float2 *slab = a.part + ((size_t) s * a.splits + j) * M;
-    for (int b = threadIdx.x; b < M; b += kThreads) slab[b] = lds.buf[b];
-
-    // ---- publish the slab, take a ticket ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        l_ticket = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (l_ticket != (unsigned) (a.splits - 1)) return;
-
-    // ---- last arriver of this stream: combine ----
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&tickets[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    sum_partials<N>(a.part + (size_t) s * a.splits * M, a.splits, lds.scratch, lds.buf);
-    if (wave == 0) {
-        wave_split_inverse<M>(lds.buf, lds.tw, lane);
-        wave_fft<M, true>(lds.buf, lds.tw, lane);
-        wave_overlap_add(reinterpret_cast<const float *>(lds.buf), 1.0f / (float) N, a.B,
-                         a.ovl + (size_t) s * a.B, a.out + (size_t) s * a.out_stride, lane);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_step_cols: the one-block step for FEW streams (latency path) and for mid-size batches, in ONE launch.
 // A workgroup owns a COLUMN slice of the spectrum (W float4 = 2W complex bins) and a partition range:
 //   grid = S * CS * PS,  CS = (N/4)/W column slices,  PS = partition splits (a.splits).
 // Thread (col, stripe) = (tid % W, tid / W) loads its column of up to 8 partitions (H row and FDL row, 16 B each)
 // in ONE round of loads; the 256/W stripes are combined by DPP row rotations + one LDS pass.  Slicing by columns
 // instead of by partitions shrinks the inter-workgroup hand-off from one whole spectrum row per workgroup
-// (k_step_split: splits * N*4 bytes per stream, read serially by the last arriver) to PS rows per stream.
+// (the partition-split kernels of rounds 1-4: splits * N*4 bytes per stream, read serially by the last arriver) to PS rows per stream.
 // The new block's forward FFT is done REDUNDANTLY by every workgroup of partition range 0 (the CUs are idle
 // anyway on this path) while its partition loads are in flight, so nothing waits for another workgroup's FFT;
 // each of them writes only its own column slice of the spectrum into the ring.
@@ -798,7 +608,8 @@ struct ColsGeom {
 //     the overlap, because ANY workgroup can turn out to be the last arriver that runs the inverse FFT.
 // Hand-off forms of k_step_cols (HO):
 //   0  write-through (sc1) slices + drained wait + ONE ticket per workgroup; the last arriver finishes the stream
-//   1  plain slices + agent-scope release / acquire fences around the ticket (the textbook form; A/B and tests)
+//      (form 1 of rounds 2-4 -- plain slices + agent-scope release / acquire fences around the ticket, the textbook form, ~3.4 us
+//      slower per step -- was the fallback for devices other than gfx950; the library is built for gfx950 only and no longer carries it)
 //   2  tagged granules (cdna_hip_programming.md Guideline 16, R2: "the data is the flag"): every float of a slice is
 //      ONE aligned 8-byte sc1 store {tag = epoch, value}; a producer exits right after issuing them -- no drain, no
 //      barrier, no ticket.  The workgroup (slice 0, range 0) of each stream is the reducer: it re-reads the stream's
@@ -809,7 +620,7 @@ struct ColsGeom {
 template <int N, int W_, int HO, int U = 8>
 __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__restrict__ tickets)
 {
-    constexpr bool SC1 = (HO == 0);
+    static_assert(HO == 0 || HO == 2, "hand-off forms: 0 write-through slices + ticket, 2 tagged granules");
     using C = ColsGeom<N, W_>;
     constexpr int M = C::M, W = C::W, CS = C::CS, TWL = C::TWL, NWAVES = kThreads / kWave;
     __shared__ float2 l_tw[TwLds<N>::SIZE];
@@ -969,8 +780,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
             __hip_atomic_store(g + 1, tag | __float_as_uint(lo.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g + 2, tag | __float_as_uint(hi.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g + 3, tag | __float_as_uint(hi.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if constexpr (SC1) { st_sc1(slab + b, lo); st_sc1(slab + b + 1, hi); }
-        else *reinterpret_cast<float4 *>(slab + b) = make_float4(lo.x, lo.y, hi.x, hi.y);
+        } else { st_sc1(slab + b, lo); st_sc1(slab + b + 1, hi); }
     }
 
     if constexpr (HO == 2) {
@@ -1030,17 +840,13 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
         return;
     }
 
-    // ---- publish: drained stores, barrier, (plain-store form: one agent-scope release), one ticket ----
+    // ---- publish: drained stores, barrier, one ticket ----
     const unsigned total = (unsigned) (CS * PS);
     IRB_STAMP(a, 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     IRB_STAMP(a, 6);
     if (tid == 0) {
-        if constexpr (!SC1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         l_ticket = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -1048,14 +854,7 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
     if (l_ticket != total - 1) return;
 
     // ---- last arriver of this stream: sum the PS slabs, inverse FFT, overlap-add ----
-    if (tid == 0) {
-        if constexpr (!SC1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __hip_atomic_store(&tickets[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if constexpr (!SC1) __syncthreads();
+    if (tid == 0) __hip_atomic_store(&tickets[s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float2 *rows = a.part + (size_t) s * PS * M;
     for (int b = tid; b < M; b += kThreads) {
         float2 v = make_float2(0.f, 0.f);
@@ -1064,11 +863,11 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
             float2 w[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                w[i] = SC1 ? ld_sc1(rows + (size_t) (r + i) * M + b) : rows[(size_t) (r + i) * M + b];
+                w[i] = ld_sc1(rows + (size_t) (r + i) * M + b);
             v.x += (w[0].x + w[1].x) + (w[2].x + w[3].x);
             v.y += (w[0].y + w[1].y) + (w[2].y + w[3].y);
         }
-        for (; r < PS; r++) v = cadd(v, SC1 ? ld_sc1(rows + (size_t) r * M + b) : rows[(size_t) r * M + b]);
+        for (; r < PS; r++) v = cadd(v, ld_sc1(rows + (size_t) r * M + b));
         l_buf[b] = v;
     }
     __syncthreads();
@@ -1093,9 +892,9 @@ __global__ __launch_bounds__(kThreads) void k_step_cols(StepArgs a, unsigned *__
 // 2*TT-1 X rows and TT accumulators in registers (per outer step: TT new X rows + TT H rows feed
 // TT*TT complex multiply-adds per bin).  HBM/L2 traffic per output drops by ~TT versus streaming.
 //   k_push_fft_batch   grid = S*t_count (block index fastest): blocks [t_first, t_first + t_count) of the call
-//   k_cmac_tiled       grid = S*ceil(T/TT)*splits: stripes own contiguous partition sub-ranges and
+//   k_cmac_tiled_pk    grid = S*ceil(T/TT)*splits: stripes own contiguous partition sub-ranges and
 //                      write their partial spectra straight from registers: part[s][j][q][M]
-//   k_ifft_ola_batch   grid = S*T: sums the nq partials of block j and of block j-1 (for its tail)
+//   k_ifft_ola_run     grid = S*ceil(T/NB): sums the partials of its blocks, inverse FFTs, overlap-add (fdl_tiled_pk.hpp)
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepArgs a, int S)
@@ -1110,6 +909,7 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_push_fft_batch(StepA
     TwiddleStage<N, kWave * NF> tws;
     tws.load(a.tw);
     if (live) wave_load_block_upto<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, a.in_len - (long) j * a.B, l_buf[wave], lane);
+    if (live && a.dbg_sums) wave_block_checksum<N>(l_buf[wave], lane, a.dbg_sums + (size_t) s * a.T + j);
     tws.store(l_tw);
     __syncthreads();
     if (!live) return;
@@ -1127,91 +927,7 @@ __device__ __forceinline__ int ring_slot(int head, int d, int R)
     return sl;
 }
 
-// one complex-pair multiply-accumulate; `first_is_packed` lanes treat the first complex of the float4
-// as packed bin 0 = two real bins: p = 0, q = h.y there (see k_cmac_tiled)
-__device__ __forceinline__ void cmac2(float4 &acc, const float4 x, const float4 h, float p, float q)
-{
-    acc.x = fmaf(x.x, h.x, acc.x);  acc.x = fmaf(-x.y, p, acc.x);
-    acc.y = fmaf(x.x, p, acc.y);    acc.y = fmaf(x.y, q, acc.y);
-    acc.z = fmaf(x.z, h.z, acc.z);  acc.z = fmaf(-x.w, h.w, acc.z);
-    acc.w = fmaf(x.z, h.w, acc.w);  acc.w = fmaf(x.w, h.z, acc.w);
-}
-
-#ifndef IRB_TILED_MIN_WAVES
-#define IRB_TILED_MIN_WAVES 4      // <= 128 VGPRs (2 spilled): 4 waves per SIMD instead of 3, +4..5 % on cache-resident calls
-#endif
-template <int N, int TT, bool NT = false>
-__global__ __launch_bounds__(kThreads, IRB_TILED_MIN_WAVES) void k_cmac_tiled(StepArgs a)
-{
-    using G = MacGeom<N>;
-    constexpr int M = N / 2;
-    const int ntiles = (a.T + TT - 1) / TT;
-    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int split = wg % a.splits, j0 = ((wg / a.splits) % ntiles) * TT, s = wg / (a.splits * ntiles);
-    const int2 si = a.stream_info[s];
-    const int set = si.x, np = si.y;
-    // the stripe index is the same for a whole wave (LW >= 64 for every supported N >= 256; smaller N are not
-    // worth tuning): telling the compiler so keeps partition indices and ring slots in scalar registers
-    const int col0 = threadIdx.x % G::LW;
-    const int stripe = G::LW >= kWave ? __builtin_amdgcn_readfirstlane(threadIdx.x / G::LW) : (int) (threadIdx.x / G::LW);
-    const int q = split * G::STRIPES + stripe;
-    // whole groups of TT partitions per worker (worker = one stripe of one split).  The H rows between
-    // np and the next multiple of TT are kept at zero by the host, so there is no remainder loop.
-    const int nG = (np + TT - 1) / TT, nW = a.splits * G::STRIPES;
-    const int sb = (int) ((long) nG * q / nW) * TT, se = (int) ((long) nG * (q + 1) / nW) * TT;
-    const float4 *H4 = reinterpret_cast<const float4 *>(a.H + (size_t) set * a.P * M);
-    const float4 *X4 = reinterpret_cast<const float4 *>(a.X + (size_t) s * a.R * M);
-
-#pragma unroll 1
-    for (int c = 0; c < G::CPT; c++) {
-        const int col = col0 + c * G::LW;
-        const bool packed = (col == 0);
-        float4 acc[TT];
-#pragma unroll
-        for (int j = 0; j < TT; j++) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-        int k0 = sb;
-        if (k0 < se) {
-            // window xr[i] = X_{t0 + base + i}, base = j0 - k0 - (TT-1)
-            float4 xr[2 * TT - 1];
-#pragma unroll
-            for (int i = TT; i < 2 * TT - 1; i++)
-                xr[i] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - (TT - 1) + i, a.R) * G::L + col);
-            for (; k0 < se; k0 += TT) {
-                // issue order = order of first use (partition u needs h[u] and, as its only NEW row, xr[TT-1-u]):
-                // loads complete in order, so the products of partition 0 can start after two loads instead of 16
-                float4 h[TT];
-#pragma unroll
-                for (int u = 0; u < TT; u++) {
-                    h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
-                    xr[TT - 1 - u] = ld16<NT>(X4 + (size_t) ring_slot(a.head, j0 - k0 - u, a.R) * G::L + col);
-                }
-                // keep the 16 loads together in front of the products: left alone, hipcc sinks every load to its first use
-                // and waits for it there (16 exposed L2 latencies per step instead of one)
-                if (IRB_TILED_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < TT; u++) {
-                    const float p = packed ? 0.0f : h[u].y;
-                    const float qq = packed ? h[u].y : h[u].x;
-#pragma unroll
-                    for (int j = 0; j < TT; j++) cmac2(acc[j], xr[j - u + TT - 1], h[u], p, qq);
-                }
-#pragma unroll
-                for (int i = 2 * TT - 2; i >= TT; i--) xr[i] = xr[i - TT];   // next step: base -= TT
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TT; j++) {
-            if (j0 + j < a.T) {
-                float4 *dst = reinterpret_cast<float4 *>(a.part + (((size_t) s * a.T + j0 + j) * a.nq + q) * M);
-                dst[col] = acc[j];
-            }
-        }
-    }
-}
-
-// one wave: sum the nq partial rows of one output block into buf (LDS)
-// Variant with ONE complex bin per lane and TT = 16 outputs per tile: half the bytes per FMA of k_cmac_tiled
+// Variant with ONE complex bin per lane and TT = 16 outputs per tile: half the bytes per FMA of round 2's two-bins-per-lane tile
 // (per 16 partitions: 32 eight-byte loads feed 256 complex MACs), at the price of 8-byte loads and ~140 VGPRs.
 template <int N, int TT>
 __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
@@ -1250,7 +966,7 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
                     h[u] = H2[(size_t) (k0 + u) * M + col];
                     xr[7 - u] = X2[(size_t) ring_slot(a.head, j0 - k0 - u, a.R) * M + col];
                 }
-                if (IRB_TILED_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);      // as in k_cmac_tiled: loads stay in front
+                __builtin_amdgcn_sched_barrier(0);                                    // loads stay in front
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const float p = packed ? 0.0f : h[u].y;
@@ -1272,6 +988,7 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
     }
 }
 
+// one wave: sum the nq partial rows of one output block into buf (LDS)
 template <int N>
 __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, int nq, float2 *buf, int lane)
 {
@@ -1302,58 +1019,6 @@ __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, in
         if (L >= kWave || col < L) reinterpret_cast<float4 *>(buf)[col] = v[c];
     }
     wave_sync();
-}
-
-// one wave per output block (s, j): IFFT of block j-1 for its tail (or the saved overlap for j = 0),
-// IFFT of block j, overlap-add; the wave of the last block also saves the new overlap.
-template <int N>
-__global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ifft_ola_batch(StepArgs a, int S)
-{
-    constexpr int M = N / 2, NF = FftGeom<N>::NF;
-    constexpr int VPL = M > kWave ? M / kWave : 1;     // tail samples per lane (B <= M)
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[NF][M];
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int item = blockIdx.x * NF + wave;
-    stage_twiddles<N>(a.tw, l_tw);
-    __syncthreads();
-    if (item >= S * a.T) return;
-    const int j = item % a.T, s = item / a.T;
-    const float scale = 1.0f / (float) N;
-    float2 *buf = l_buf[wave];
-    const float *y = reinterpret_cast<const float *>(buf);
-    float tail[VPL];
-    if (j > 0) {
-        wave_sum_rows<N>(a.part + ((size_t) s * a.T + (j - 1)) * a.nq * M, a.nq, buf, lane);
-        wave_split_inverse<M>(buf, l_tw, lane);
-        wave_fft<M, true>(buf, l_tw, lane);
-#pragma unroll
-        for (int i = 0; i < VPL; i++) {
-            const int n = lane + i * kWave;
-            tail[i] = n < a.B ? y[a.B + n] * scale : 0.0f;
-        }
-        wave_sync();
-    } else {
-        const float *ov = a.ovl + (size_t) s * a.B;
-#pragma unroll
-        for (int i = 0; i < VPL; i++) {
-            const int n = lane + i * kWave;
-            tail[i] = n < a.B ? ov[n] : 0.0f;
-        }
-    }
-    wave_sum_rows<N>(a.part + ((size_t) s * a.T + j) * a.nq * M, a.nq, buf, lane);
-    wave_split_inverse<M>(buf, l_tw, lane);
-    wave_fft<M, true>(buf, l_tw, lane);
-    float *out = a.out + (size_t) s * a.out_stride + (size_t) j * a.B;
-#pragma unroll
-    for (int i = 0; i < VPL; i++) {
-        const int n = lane + i * kWave;
-        if (n < a.B) out[n] = y[n] * scale + tail[i];
-    }
-    if (j == a.T - 1) {
-        float *on = a.ovl_next + (size_t) s * a.B;
-        for (int n = lane; n < a.B; n += kWave) on[n] = y[a.B + n] * scale;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         __syncthreads();
     }
     if (live) wave_load_block_upto<M>(a.in + (long) s * a.in_stride + (long) j * a.B, a.B, a.in_len - (long) j * a.B, l_buf[wave], lane);
+    if (live && a.dbg_sums) wave_block_checksum<N>(l_buf[wave], lane, a.dbg_sums + (size_t) s * a.T + j);
     tws.store(l_tw);
     __syncthreads();
     if (live) {

@@ -1,7 +1,7 @@
 // fdl_tiled_pk.hpp -- the time-tiled multiply-accumulate of calls that carry T > 1 blocks per stream, second
 // generation (round 3), and the inverse-FFT / overlap-add kernel that follows it.  Included by fdl_kernels.hpp.
 //
-// What round 2's k_cmac_tiled<N,8> was bound by (tools/valu_peak.hip + its own byte count): a lane multiplies
+// What round 2's tile (k_cmac_tiled<N,8>, removed in round 5) was bound by (tools/valu_peak.hip + its own byte count): a lane multiplies
 // 8 partitions x 8 outputs x 2 bins per step = 512 v_fma_f32 from 16 row loads of 16 B, i.e. 4 flop per byte
 // through the CU's vector L1 (64 B/clk): at the fp32 vector peak the L1 would have to deliver exactly its own
 // peak, so the kernel sat where two equally loaded pipes without perfect overlap sit (0.36 of 157 TFLOP/s).
@@ -12,7 +12,7 @@
 //   * keeps a 16-output tile: per U partitions 2U row loads feed 16 U complex products per bin (8 flop per
 //     L1 byte), the X window lives in a register ring whose indices are compile-time constants (the loop is
 //     unrolled over the ring period), so the window never moves between registers.
-// The arithmetic per accumulator is the same FMA sequence as cmac2(): results are bit-identical to k_cmac_tiled.
+// The arithmetic per accumulator is the same FMA sequence as that kernel's: results were bit-identical to it (tested until its removal).
 #pragma once
 
 namespace irb {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void tile_step(const float4 *__restrict__ H4, const f
         h[u] = ld16<NT>(H4 + (size_t) (k0 + u) * G::L + col);
         xr[TP::phys(U - 1 - u, S)] = ld16<NT>(X4 + (size_t) ring_slot(head, j0 - k0 - u, R) * G::L + col);
     }
-    __builtin_amdgcn_sched_barrier(0);         // loads first (see k_cmac_tiled)
+    __builtin_amdgcn_sched_barrier(0);         // loads first
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const v2f_t hz = {h[u].z, h[u].w};
@@ -99,7 +99,7 @@ __device__ __forceinline__ void tile_run(const float4 *__restrict__ H4, const fl
         tile_period<N, TT, U, 0, NT, PACKED>(H4, X4, col, k0, j0, head, R, xr, acc, packed);
 }
 
-// grid = S * ceil(T/TT) * splits, as k_cmac_tiled.  The stripes of a workgroup (partition sub-ranges of the same outputs)
+// grid = S * ceil(T/TT) * splits.  The stripes of a workgroup (partition sub-ranges of the same outputs)
 // are added through LDS before anything leaves the CU, so a workgroup writes ONE partial spectrum per output:
 // part[s][j][split][M] (round 2 wrote one per stripe: at one stream x 3750 blocks that was 61 MB of partials written,
 // flushed at the kernel boundary and read back by the inverse-FFT kernel -- more bytes than H and the FDL together).

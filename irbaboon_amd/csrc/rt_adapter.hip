@@ -14,6 +14,7 @@
 //    ring grows, :213-215) and resets outputSampleIndex when it would index past the new host block.
 //  * irb_rt_set_ir checks the IR length instead of reading out of bounds (:457).
 #include "../../include/irb_fdl.h"
+#include "irb_env.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -123,8 +124,8 @@ int irb_rt_prepare_to_play(irb_rt *p, int samples_per_block)                    
     // ... and, where the BAR lets the host store into device memory, by a workgroup that stays resident between callbacks (no launch
     // per callback; it leaves by itself 20 ms after the last callback); IRB_RT_RESIDENT=0: one launch per callback
     cfg.flags = IRB_FDL_HOST_IO | IRB_FDL_STEPWISE | IRB_FDL_RESIDENT;
-    if (const char *v = std::getenv("IRB_RT_HOST_IO")) { if (std::atoi(v) == 0) cfg.flags &= ~IRB_FDL_HOST_IO; }     // A/B
-    if (const char *v = std::getenv("IRB_RT_ONE_LAUNCH")) { if (std::atoi(v) == 0) cfg.flags |= IRB_FDL_NO_RT_KERNEL; }   // A/B
+    if (dbg_int("rt_host_io", 1) == 0) cfg.flags &= ~IRB_FDL_HOST_IO;          // A/B (IRB_DEBUG, irb_env.hpp)
+    if (dbg_int("rt_one_launch", 1) == 0) cfg.flags |= IRB_FDL_NO_RT_KERNEL;   // A/B
     if (const char *v = std::getenv("IRB_RT_RESIDENT")) { if (std::atoi(v) == 0) cfg.flags &= ~IRB_FDL_RESIDENT; }        // A/B
     return irb_fdl_create(&cfg, &p->eng);
 }

@@ -163,11 +163,10 @@ def test_config5_full_size_default_smoothing_and_inversion():
 @pytest.mark.parametrize("fuse", ["0", "3"])
 @pytest.mark.parametrize("tile", ["0", "4", "8", "16"])
 def test_large_fft_tile_heights(monkeypatch, tile, fuse):
-    """every tiling of the four-step passes (IRB_LFFT_TILE: rows / columns per workgroup; 0 = one wave per item), with the
-    real split as its own launch or fused into the tiled passes (IRB_LFFT_FUSE_SPLIT: bit 0 inverse, bit 1 forward),
+    """every tiling of the four-step passes (IRB_DEBUG lfft_tile: rows / columns per workgroup; 0 = one wave per item), with the
+    real split as its own launch or fused into the tiled passes (lfft_fuse_split: bit 0 inverse, bit 1 forward),
     gives the same transform: 2^14 .. 2^21 points"""
-    monkeypatch.setenv("IRB_LFFT_TILE", tile)
-    monkeypatch.setenv("IRB_LFFT_FUSE_SPLIT", fuse)
+    monkeypatch.setenv("IRB_DEBUG", f"lfft_tile={tile},lfft_fuse_split={fuse}")
     ib.lib().irb_release_cached_plans()
     for n in (1 << 14, 1 << 17, 1 << 20, 1 << 21):
         x = white_noise(n + int(tile), n)

@@ -15,6 +15,14 @@ from irbaboon_amd import FdlEngine, RtConvolver, _lib, convolvePeriodic
 from irbaboon_amd.synth import decaying_ir, delta_ir, white_noise
 from util import RMS_TOL, direct_f64, rel_rms, written_samples
 
+
+def _dbg(monkeypatch, **kv):
+    """the library's internal knobs: ONE variable, IRB_DEBUG="name=value,..." (tests and tools only)"""
+    if kv:
+        monkeypatch.setenv("IRB_DEBUG", ",".join(f"{k}={v}" for k, v in kv.items()))
+    else:
+        monkeypatch.delenv("IRB_DEBUG", raising=False)
+
 pytestmark = pytest.mark.gpu
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "convolve_cases.npz"))
@@ -41,13 +49,12 @@ ENGINE_CASES = [
 
 
 @pytest.mark.parametrize("tmax", [1, 7], ids=["step", "tiled7"])
-@pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, _lib.FORCE_COLS, 0],
-                         ids=["fused", "split", "split3", "cols", "auto"])
+@pytest.mark.parametrize("flags", [_lib.FORCE_FUSED, _lib.FORCE_COLS, 0], ids=["fused", "cols", "auto"])
 @pytest.mark.parametrize("case", ENGINE_CASES, ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
 def test_engine_streaming_matches_oracle(case, flags, tmax):
     """tmax=1: every block is a one-block step, so `flags` really selects k_step_fused / k_step_fused_pair /
-    k_step_split / the three-launch split kernels; tmax=7: chunks of 7 blocks go through the time-tiled kernels
-    (k_push_fft_batch, k_cmac_tiled, k_ifft_ola_batch) and only a 1-block remainder is a step."""
+    k_step_cols; tmax=7: chunks of 7 blocks go through the time-tiled kernels (k_tile8_fused, or k_push_fft_batch,
+    k_cmac_tiled_pk, k_ifft_ola_run) and only a 1-block remainder is a step."""
     I, C, Cir, B, Lh, T = case
     x = _streams(I, C, T * B, 100)
     irs = [np.stack([decaying_ir(9000 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
@@ -121,14 +128,6 @@ def test_convolve_periodic_edge_cases():
     x = white_noise(2, 1)[None]                                                          # single sample
     y = convolvePeriodic(x, h, 16, keep_reference_tail=False)
     assert rel_rms(y, direct_f64(x, h)) < RMS_TOL
-
-
-def _dbg(monkeypatch, **kv):
-    """the library's internal knobs: ONE variable, IRB_DEBUG="name=value,..." (tests and tools only)"""
-    if kv:
-        monkeypatch.setenv("IRB_DEBUG", ",".join(f"{k}={v}" for k, v in kv.items()))
-    else:
-        monkeypatch.delenv("IRB_DEBUG", raising=False)
 
 
 def _form(monkeypatch, form):
@@ -436,7 +435,7 @@ def test_rt_adapter_matches_oracle(host_block):
 @pytest.mark.parametrize("host_block", [64, 100, 256, 512, 1024])
 def test_rt_one_launch_callback_matches_two_launch_path_and_oracle(monkeypatch, host_block):
     """The callback as ONE kernel launch (k_rt_pair: rolling IR refresh + every block of the callback + completion word,
-    Source/PluginProcessor.cpp:452-518) against the refresh-launch + step-launch sequence (IRB_RT_ONE_LAUNCH=0) and, for
+    Source/PluginProcessor.cpp:452-518) against the refresh-launch + step-launch sequence (IRB_DEBUG=rt_one_launch=0) and, for
     host blocks the reference handles causally (<= 256), against the restated processBlock -- with the IR replaced in
     mid-stream, so that the FDL meets a mixture of old and new partitions exactly as the reference's does."""
     irs = [decaying_ir(5, 8 * 256), decaying_ir(6, 8 * 256)[::-1].copy()]
@@ -445,7 +444,7 @@ def test_rt_one_launch_callback_matches_two_launch_path_and_oracle(monkeypatch, 
     outs, counts = [], []
     monkeypatch.setenv("IRB_RT_RESIDENT", "0")            # this test is about the launches; the resident server has its own
     for one in ("1", "0"):
-        monkeypatch.setenv("IRB_RT_ONE_LAUNCH", one)
+        _dbg(monkeypatch, rt_one_launch=one)
         gpu = RtConvolver(2, 256, 2048)
         gpu.prepareToPlay(host_block)
         ref = oracle.RtProcessor(2, 256, 2048)
@@ -551,10 +550,9 @@ def test_rt_mono_plugin_callback_on_every_path(monkeypatch, host_block):
     n_cb = max(24, 256 * 30 // host_block)
     x = white_noise(47, n_cb * host_block)[None, :].copy()
     outs, per_cb = {}, {}
-    for mode, env in (("resident", {"IRB_RT_RESIDENT": "1", "IRB_RT_ONE_LAUNCH": "1"}), ("one_launch", {"IRB_RT_RESIDENT": "0", "IRB_RT_ONE_LAUNCH": "1"}),
-                      ("launch_pairs", {"IRB_RT_RESIDENT": "0", "IRB_RT_ONE_LAUNCH": "0"})):
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+    for mode, resident, one in (("resident", "1", 1), ("one_launch", "0", 1), ("launch_pairs", "0", 0)):
+        monkeypatch.setenv("IRB_RT_RESIDENT", resident)
+        _dbg(monkeypatch, rt_one_launch=one)
         gpu = RtConvolver(1, 256, 2048)
         gpu.prepareToPlay(host_block)
         ref = oracle.RtProcessor(1, 256, 2048)
@@ -693,7 +691,7 @@ def test_resident_server_does_not_stall_other_handles():
     one-launch form meanwhile).  Phase 1: A driven block by block from Python, every sample checked against the restated
     processBlock.  Phase 2: A's callbacks issued and timed in C (irb_rt_time_callbacks: no interpreter lock between the audio
     thread and its clock) while the same work runs again -- A's callbacks must stay inside their 5.3 ms period.
-    The measured times go to gpurun_out/resident_vs_process.txt (IRB_DEVICE_QUIET=0: the same without the brackets, recorded, not asserted)."""
+    The measured times go to gpurun_out/resident_vs_process.txt (IRB_DEBUG=device_quiet=0: the same without the brackets, recorded, not asserted)."""
     import threading
     import time
     ir = decaying_ir(5, 8 * 256)
@@ -778,7 +776,7 @@ def test_resident_server_does_not_stall_other_handles():
                  f"median {np.median(cb):.1f} us, p99 {np.percentile(cb, 99):.1f} us, p99.9 {np.percentile(cb, 99.9):.1f} us, max {cb.max():.1f} us "
                  f"(slowest five: {[(int(i), round(float(cb[i]), 1)) for i in np.argsort(cb)[-5:][::-1]]}); "
                  f"kernel launches {c1[1] - c0[1]} (callbacks served by one launch each while a quiet section was open, server restarts)")
-    unprotected = os.environ.get("IRB_DEVICE_QUIET") == "0"      # diagnostic run: quiet sections switched off, times recorded, not asserted
+    unprotected = "device_quiet=0" in os.environ.get("IRB_DEBUG", "")      # diagnostic run: quiet sections switched off, times recorded, not asserted
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "resident_vs_process" + ("_unprotected" if unprotected else "") + ".txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
@@ -990,10 +988,10 @@ def test_two_engines_in_two_threads():
     assert len(res) == 4 and max(res.values()) < RMS_TOL
 
 
-def test_split_handoff_stress_under_load():
-    """The single-launch split path hands slabs between workgroups (release/acquire + ticket).  Hammer it:
-    many streams x splits, hundreds of steps, while another engine streams from HBM on a second HIP stream
-    (uneven load, warm caches).  A stale or missing slab is an O(1) error; the fused kernel is the reference."""
+def test_cols_handoff_stress_under_load():
+    """The column-sliced step hands slices between workgroups (write-through stores + ticket).  Hammer it:
+    many streams x workgroups, hundreds of steps, while another engine streams from HBM on a second HIP stream
+    (uneven load, warm caches).  A stale or missing slice is an O(1) error; the fused kernel is the reference."""
     import threading
     I, B, Lh, T = 48, 256, 24000, 240
     x = _streams(I, 1, T * B, 4242)
@@ -1014,7 +1012,7 @@ def test_split_handoff_stress_under_load():
     th.start()
     try:
         outs = {}
-        for name, flags in (("fused", _lib.FORCE_FUSED), ("split", _lib.FORCE_SPLIT), ("cols", _lib.FORCE_COLS)):
+        for name, flags in (("fused", _lib.FORCE_FUSED), ("cols", _lib.FORCE_COLS)):
             with FdlEngine(I, 1, B, Lh, flags=flags) as eng:
                 for i in range(I):
                     eng.set_ir(i, irs[i])
@@ -1025,10 +1023,9 @@ def test_split_handoff_stress_under_load():
         stop.set()
         th.join()
     for i in range(I):
-        assert rel_rms(outs["split"][i], outs["fused"][i]) < 2e-6
         assert rel_rms(outs["cols"][i], outs["fused"][i]) < 2e-6
     ref, _ = oracle.convolve_periodic(x[:1], irs[0][None], B)
-    assert rel_rms(outs["split"][0], ref[0, :T * B]) < RMS_TOL
+    assert rel_rms(outs["cols"][0], ref[0, :T * B]) < RMS_TOL
 
 
 def test_packed_host_api_matches_pointer_api():
@@ -1100,13 +1097,13 @@ def test_multi_device_group_matches_single_engine():
 @pytest.mark.parametrize("B,Lh,T", [(256, 5000, 40), (128, 3000, 33), (512, 6000, 16), (64, 900, 50), (1024, 9000, 17)])
 def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
     """k_cmac_tiled1 (one bin per lane, 16 outputs per tile) is chosen only for HBM-sized batches; force it here
-    (IRB_TILED1=1) on small cases and compare with the oracle and with the default tiled kernel."""
+    (IRB_DEBUG=tiled1=1) on small cases and compare with the oracle and with the default tiled kernel."""
     I, C = 3, 2
     x = _streams(I, C, T * B, 555)
     irs = [np.stack([decaying_ir(560 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
     for force in ("1", "0"):
-        monkeypatch.setenv("IRB_TILED1", force)
+        _dbg(monkeypatch, tiled1=force)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
@@ -1124,7 +1121,7 @@ def test_one_bin_tiled_kernel(monkeypatch, B, Lh, T):
                          ids=lambda v: str(v))
 def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
     """k_cmac_mfma (the time axis of every bin as Toeplitz-block products on v_mfma_f32_16x16x4_f32; the default for calls of
-    >= 256 blocks, forced here from 2 blocks on with IRB_TILED_MFMA_MIN_T) against the packed-FMA kernel and the oracle: calls
+    >= 256 blocks, forced here from 2 blocks on with IRB_DEBUG=mfma_min_t=2) against the packed-FMA kernel and the oracle: calls
     that end inside the first 256-block tile or span several, partition counts around the 16-tap chunk edges (and 1, 2, 16 partitions:
     a single Toeplitz chunk, whose upper triangle is all padding), several partition splits (P = 600), packed bin 0, stereo IRs,
     history across calls (one signal as two calls)."""
@@ -1132,7 +1129,7 @@ def test_matrix_core_tiled_kernel(monkeypatch, I, C, B, Lh, T):
     irs = [np.stack([decaying_ir(960 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
     for min_t in ("2", "0"):
-        monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", min_t)
+        _dbg(monkeypatch, mfma_min_t=min_t)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
@@ -1174,25 +1171,25 @@ def test_matrix_core_path_properties_at_the_full_baseline_size():
 
 def test_matrix_core_plan_of_two_regions_in_one_grid(monkeypatch):
     """A call whose tiles do not fill whole rounds of workgroups is multiplied as two regions (the full rounds unsplit, the remaining
-    tiles with their partitions split; fdl_engine.hip: mfma_plan).  By default ONE k_cmac_mfma grid carries both (the second region's
-    workgroups last in dispatch order); IRB_TILED_MFMA_ONE_GRID=0 launches them one after the other.  Same arithmetic either way:
-    bit-identical outputs, one launch fewer, and the oracle's result.  (8 workgroups per round here, so 5 tiles = 4 + 1.)"""
-    I, C, B, Lh, T = 1, 1, 32, 100 * 32, 1280
-    x = _streams(I, C, T * B, 4242)
+    tiles with their partitions split; fdl_engine.hip: mfma_plan), both carried by ONE k_cmac_mfma grid (the second region's
+    workgroups last in dispatch order).  8 workgroups per round here, so 5 tiles = 4 + 1: one multiply launch, the packed-FMA kernel's
+    result to rounding, the oracle's within tolerance -- and a call of exactly 4 tiles (one region) likewise."""
+    I, C, B, Lh = 1, 1, 32, 100 * 32
     h = decaying_ir(4243, Lh)[None]
-    monkeypatch.setenv("IRB_TILED_MFMA_WGS", "8")
-    outs, launches = [], []
-    for one in ("1", "0"):
-        monkeypatch.setenv("IRB_TILED_MFMA_ONE_GRID", one)
-        with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
-            eng.set_ir(0, h)
-            assert eng.mac_kernel_name(T) == "k_cmac_mfma"
-            n0 = eng.counters()[0]
-            outs.append(eng.process(x))
-            launches.append(eng.counters()[0] - n0)
-    assert np.array_equal(outs[0], outs[1]) and launches[1] == launches[0] + 1
-    ref, _ = oracle.convolve_periodic(x, h, B)
-    assert rel_rms(outs[0][0], ref[0, :T * B]) < RMS_TOL
+    for T in (1280, 1024):
+        x = _streams(I, C, T * B, 4242)
+        outs = []
+        for dbg in ({"mfma_wgs": 8}, {"mfma_min_t": 0}):
+            _dbg(monkeypatch, **dbg)
+            with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
+                eng.set_ir(0, h)
+                assert eng.mac_kernel_name(T) == ("k_cmac_mfma" if "mfma_wgs" in dbg else "k_cmac_tiled_pk<16,8>")
+                n0 = eng.counters()[0]
+                outs.append(eng.process(x))
+                assert eng.counters()[0] - n0 == 3                  # forward FFTs, ONE multiply, inverse FFTs
+        assert rel_rms(outs[0], outs[1]) < 2e-6
+        ref, _ = oracle.convolve_periodic(x, h, B)
+        assert rel_rms(outs[0][0], ref[0, :T * B]) < RMS_TOL
 
 
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 64, 6000, 600), (1, 2, 32, 3000, 1100), (2, 1, 128, 12800, 513), (1, 1, 64, 3000, 256), (1, 2, 32, 2000, 390)],
@@ -1202,14 +1199,13 @@ def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B,
     kernel's, so the two outputs differ in the last bits) unless its last 256-block tile would be mostly padding (257 .. 341 blocks),
     shorter calls of the same engine do not; both against the oracle, and one signal fed as a long and a short call continues
     seamlessly (the FDL history is shared by both kernels)."""
-    for k in ("IRB_TILED_MFMA_MIN_T", "IRB_TILED_MFMA_WGS", "IRB_TILED_MFMA_MIN_CHUNKS"):
-        monkeypatch.delenv(k, raising=False)
+    _dbg(monkeypatch)
     x = _streams(I, C, (T + 40) * B, 975)
     irs = [np.stack([decaying_ir(980 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", "0")
+            _dbg(monkeypatch, mfma_min_t=0)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
@@ -1231,14 +1227,14 @@ def test_long_calls_take_the_matrix_core_kernel_by_default(monkeypatch, I, C, B,
 @pytest.mark.parametrize("I,C,B,Lh,T", [(1, 1, 256, 9000, 67), (2, 2, 128, 3000, 33), (1, 1, 512, 6000, 16), (3, 1, 64, 900, 50),
                                         (1, 2, 1024, 9000, 17), (1, 1, 2048, 9000, 5)])
 def test_packed_fma_tiled_kernel(monkeypatch, I, C, B, Lh, T):
-    """k_cmac_tiled_pk (v_pk_fma_f32, register-ring window, stripes added in LDS; the default, IRB_TILED_KERNEL=1)
-    against round 2's k_cmac_tiled (IRB_TILED_KERNEL=0) and the oracle: calls that end inside a tile, partition
-    counts that are not a multiple of the ring period, packed bin 0, one call split in two (FDL history across calls)."""
+    """k_cmac_tiled_pk (v_pk_fma_f32, register-ring window, stripes added in LDS; calls of 2-255 blocks) against the
+    matrix-core kernel forced onto the same call and the oracle: calls that end inside a tile, partition counts that are
+    not a multiple of the ring period, packed bin 0, one call split in two (FDL history across calls)."""
     x = _streams(I, C, T * B, 755)
     irs = [np.stack([decaying_ir(760 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     outs = []
-    for k in ("1", "0"):
-        monkeypatch.setenv("IRB_TILED_KERNEL", k)
+    for k in ("pk", "mfma"):
+        _dbg(monkeypatch, **({"mfma_min_t": 2} if k == "mfma" else {}))
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
@@ -1266,7 +1262,7 @@ def test_non_finite_sample_stays_inside_the_documented_window(monkeypatch, min_t
     P = Lh // B
     x = white_noise(8700, T * B)[None].copy()
     h = decaying_ir(8701, Lh)[None]
-    monkeypatch.setenv("IRB_TILED_MFMA_MIN_T", min_t)
+    _dbg(monkeypatch, mfma_min_t=min_t)
     with FdlEngine(1, 1, B, Lh, max_blocks_per_call=T) as eng:
         eng.set_ir(0, h)
         clean = eng.process(x)
@@ -1286,26 +1282,23 @@ def test_non_finite_sample_stays_inside_the_documented_window(monkeypatch, min_t
 def test_single_tile_calls_with_non_temporal_rows(monkeypatch, B, Lh, T):
     """Calls of at most 8 blocks use the 8-output tile (k_cmac_tiled_pk<N,8,4>: a 16-output tile would multiply outputs nobody
     keeps), longer ones the 16-output tile; HBM-sized batches with one tile per stream read their rows with non-temporal loads
-    (the bench's 2048 x 8-blocks entry).  Both tiles, with and without the non-temporal variant forced, against the oracle and
-    against each other and round 2's kernel."""
+    (the bench's 2048 x 8-blocks entry).  Both tiles, with and without the non-temporal variant forced, as one launch
+    (k_tile8_fused) and as three, against the oracle and against each other."""
     I, C = 3, 1
     x = _streams(I, C, 3 * T * B, 8500)                 # three calls of T blocks: the FDL and the overlap carry over between them
     irs = [decaying_ir(8510 + i, Lh)[None] for i in range(I)]
     outs, kernels = [], []
-    # (non-temporal rows, tiled kernel generation, 8-output tile, one-launch form k_tile8_fused)
-    for nt, kern, tt8, fused in (("1", "1", "1", "1"), ("0", "1", "1", "1"), ("1", "1", "1", "0"), ("0", "1", "1", "0"), ("1", "1", "0", "1"), ("1", "0", "1", "1")):
-        monkeypatch.setenv("IRB_FUSED_NT", nt)
-        monkeypatch.setenv("IRB_TILED_KERNEL", kern)
-        monkeypatch.setenv("IRB_TILED_TT8", tt8)
-        monkeypatch.setenv("IRB_TILED_FUSED8", fused)
+    # (non-temporal rows, one-launch form k_tile8_fused)
+    for nt, fused in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        _dbg(monkeypatch, fused_nt=nt, tiled_fused8=fused)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=T) as eng:
             kernels.append(eng.mac_kernel_name(T))
             for i in range(I):
                 eng.set_ir(i, irs[i])
             outs.append(eng.process(x))
-    # calls of <= 8 blocks run as ONE launch by default, as three launches with IRB_TILED_FUSED8=0; 12-block calls never fuse
+    # calls of <= 8 blocks run as ONE launch by default, as three launches with IRB_DEBUG=tiled_fused8=0; 12-block calls never fuse
     assert kernels[0] == kernels[1] == ("k_tile8_fused" if T <= 8 else "k_cmac_tiled_pk<16,8>")
-    assert kernels[2] == ("k_cmac_tiled_pk<8,4>" if T <= 8 else "k_cmac_tiled_pk<16,8>") and kernels[5] == "k_cmac_tiled<8>"
+    assert kernels[2] == kernels[3] == ("k_cmac_tiled_pk<8,4>" if T <= 8 else "k_cmac_tiled_pk<16,8>")
     for y in outs[1:]:
         assert rel_rms(y, outs[0]) < 2e-6
     for i in range(I):
@@ -1321,15 +1314,14 @@ def test_single_tile_calls_with_non_temporal_rows(monkeypatch, B, Lh, T):
                          ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
 def test_non_temporal_fused_and_pair_kernels(monkeypatch, case):
     """k_step_fused<N,2,true> and k_step_fused_pair<N,true> (non-temporal row loads) are chosen only for working
-    sets beyond the Infinity Cache -- the bench's headline kernel.  Force them (IRB_FUSED_NT=1, read at create) on
+    sets beyond the Infinity Cache -- the bench's headline kernel.  Force them (IRB_DEBUG=fused_nt=1, read at create) on
     small cases: N = 256, 512, 1024; mono, stereo IR (unpaired) and stereo audio + mono IR (paired)."""
     I, C, Cir, B, Lh, T = case
     x = _streams(I, C, T * B, 6100)
     irs = [np.stack([decaying_ir(6200 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
     outs = []
     for nt, u in (("1", "2"), ("0", "2"), ("1", "2"), ("1", "4"), ("0", "4")):
-        monkeypatch.setenv("IRB_FUSED_NT", nt)
-        monkeypatch.setenv("IRB_FUSED_U", u)          # rows in flight per thread of k_step_fused (4: the default up to 256 streams)
+        _dbg(monkeypatch, fused_nt=nt, fused_u=u)       # fused_u: rows in flight per thread of k_step_fused (4: the default up to 256 streams)
         with FdlEngine(I, C, B, Lh, max_blocks_per_call=1, flags=_lib.FORCE_FUSED) as eng:
             for i in range(I):
                 eng.set_ir(i, irs[i])
@@ -1394,12 +1386,11 @@ def test_cfg3_streaming_geometry_split_path():
         assert rel_rms(til.process(x), y) < 2e-6
 
 
-@pytest.mark.parametrize("flags", [_lib.FORCE_SPLIT, _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, _lib.FORCE_COLS, 0],
-                         ids=["split", "split3", "cols", "auto"])
-def test_split_path_with_fewer_partitions_than_splits(flags):
-    """The split count comes from the engine's CAPACITY (max_ir_len), the partitions in use from the IR that was
-    set.  An IR with np < splits used to leave partition 0 to a later split, which read ring slot `head` while
-    split 0 was still writing it.  np in {1, 2, splits-1, splits, splits+1} and a P=1 engine."""
+@pytest.mark.parametrize("flags", [_lib.FORCE_COLS, 0], ids=["cols", "auto"])
+def test_multi_workgroup_step_with_fewer_partitions_than_workgroups(flags):
+    """The workgroup count of a stream's step comes from the engine's CAPACITY (max_ir_len), the partitions in use from the IR
+    that was set.  An IR with np < workgroups used to leave partition 0 to a later workgroup, which read ring slot `head` while
+    the first was still writing it.  np in {1, 2, splits-1, splits, splits+1} and a P=1 engine."""
     B, cap = 128, 480000
     T = 12
     x = _streams(1, 2, T * B, 7300)
@@ -1417,7 +1408,7 @@ def test_split_path_with_fewer_partitions_than_splits(flags):
             ref, _ = oracle.convolve_periodic(x, h, B)
             for c in range(2):
                 assert rel_rms(y[c], ref[c, :T * B]) < RMS_TOL, (np_, sp)
-    with FdlEngine(2, 1, 256, 200, max_blocks_per_call=1, flags=flags or _lib.FORCE_SPLIT) as one:      # P = 1, several workgroups per stream
+    with FdlEngine(2, 1, 256, 200, max_blocks_per_call=1, flags=_lib.FORCE_COLS) as one:      # P = 1, several workgroups per stream
         assert one.info.partitions == 1 and one.info.splits >= 2
         xs = _streams(2, 1, 8 * 256, 7500)
         hs = [decaying_ir(7600 + i, 200) for i in range(2)]
@@ -1456,20 +1447,18 @@ def test_bench_multi_gpu_code_path_rehearsal(n, inst):
     assert d["environment"]["library"].endswith("libirbfdl.so") and d["environment"]["irb_env"].get("IRB_BENCH_SHARE_DEVICE") == "1"
 
 
-@pytest.mark.parametrize("w,ho,ps", [(4, 0, 1), (4, 2, 1), (4, 0, 5), (4, 2, 5), (4, 1, 3), (16, 0, 2), (16, 2, 2), (16, 2, 16), (16, 1, 1),
-                                     (64, 0, 1), (64, 2, 1), (64, 1, 4), (64, 0, 7), (64, 2, 7)])
+@pytest.mark.parametrize("w,ho,ps", [(4, 0, 1), (4, 2, 1), (4, 0, 5), (4, 2, 5), (4, 0, 3), (16, 0, 2), (16, 2, 2), (16, 2, 16), (16, 0, 1),
+                                     (64, 0, 1), (64, 2, 1), (64, 2, 4), (64, 0, 7), (64, 2, 7)])
 @pytest.mark.parametrize("case", [(1, 1, 1, 256, 9000, 20), (2, 2, 2, 128, 5000, 24), (3, 1, 1, 512, 9000, 9), (1, 2, 1, 64, 700, 30),
                                   (2, 1, 1, 1024, 9000, 7), (1, 1, 1, 16, 100, 40), (2, 1, 1, 100, 950, 21)],
                          ids=lambda c: "I%d_C%d_irC%d_B%d_Lh%d_T%d" % c)
 def test_column_sliced_step_variants(monkeypatch, case, w, ho, ps):
     """k_step_cols in every shape the engine can choose: slice widths 4 / 16 / 64 float4 columns (clamped to the row
-    for small N); the three hand-off forms (0 write-through slices + ticket, 1 release/acquire fences + ticket,
-    2 tagged granules swept by a fixed reducer); 1..16 partition splits (also more splits than partitions per stripe,
+    for small N); both hand-off forms (0 write-through slices + ticket, 2 tagged granules swept by a fixed reducer);
+    1..16 partition splits (also more splits than partitions per stripe,
     ranges that need several load rounds, and empty ranges)."""
     I, C, Cir, B, Lh, T = case
-    monkeypatch.setenv("IRB_COLW", str(w))
-    monkeypatch.setenv("IRB_COLS_HANDOFF", str(ho))
-    monkeypatch.setenv("IRB_PSPLITS", str(ps))
+    _dbg(monkeypatch, colw=w, cols_handoff=ho, psplits=ps)
     x = _streams(I, C, T * B, 9100)
     irs = [np.stack([decaying_ir(9200 + 2 * i + c, Lh) for c in range(Cir)]) for i in range(I)]
     with FdlEngine(I, C, B, Lh, max_blocks_per_call=1, flags=_lib.FORCE_COLS) as eng:
@@ -1533,7 +1522,7 @@ def test_column_sliced_handoff_under_uneven_load():
 @pytest.mark.parametrize("flags", [0, _lib.HOST_IO | _lib.STEPWISE], ids=["copy_mode", "host_io_stepwise"])
 def test_granule_handoff_timeout_is_reported_and_recoverable(monkeypatch, flags):
     """The tagged-granule hand-off of k_step_cols (the default for few streams, the plug-in's long-IR engines included) spins
-    on other workgroups' stores with a 50 ms bound.  IRB_DEBUG_DROP_GRANULES=3 makes one producer of the third launch
+    on other workgroups' stores with a 50 ms bound.  IRB_DEBUG=drop_granules=3 makes one producer of the third launch
     withhold its granules: that launch must END (no hang), the blocking call must report IRB_ERR_STATE exactly once, and
     after irb_fdl_reset the handle must produce correct samples again.
     flags = HOST_IO|STEPWISE is the shape the plug-in adapter creates for a long IR (Source/PluginProcessor.cpp:452-518 through
@@ -1543,8 +1532,7 @@ def test_granule_handoff_timeout_is_reported_and_recoverable(monkeypatch, flags)
     B, Lh, T = 256, 96000, 6
     P = Lh // B
     x, h = white_noise(8100, T * B)[None], decaying_ir(8101, Lh)[None]
-    monkeypatch.setenv("IRB_DEBUG_DROP_GRANULES", "3")
-    monkeypatch.setenv("IRB_COLS_HANDOFF", "2")
+    _dbg(monkeypatch, drop_granules=3, cols_handoff=2)
     rt_shape = flags != 0
     with FdlEngine(1, 1, B, Lh, max_blocks_per_call=1, flags=flags) as eng:
         assert eng.info.splits > 1                                   # a multi-workgroup step: there is a hand-off to lose
@@ -1585,7 +1573,7 @@ def test_back_to_back_steps_without_host_sync(monkeypatch, geom, ho):
     tags advanced by the kernels themselves).  96 steps, then one download, vs float64 FFT convolution."""
     I, C, B, Lh = geom
     T = 96
-    monkeypatch.setenv("IRB_COLS_HANDOFF", ho)
+    _dbg(monkeypatch, cols_handoff=ho)
     x = _streams(I, C, T * B, 8800)
     irs = [np.stack([decaying_ir(8900 + 2 * i + c, Lh) for c in range(C)]) for i in range(I)]
     with FdlEngine(I, C, B, Lh, max_blocks_per_call=T, flags=_lib.FORCE_COLS) as eng:

@@ -24,7 +24,9 @@ for k in range(shapes):
     for key in list(os.environ):
         if key.startswith("IRB_"):
             os.environ.pop(key)
-    env = {"IRB_TILED_MFMA_MIN_T": str(rng.choice([2, 256])), "IRB_OFFLINE_DIRECT": str(rng.choice([0, 1, 1]))}
+    env = {"IRB_DEBUG": "mfma_min_t=" + str(rng.choice([2, 256]))}
+    if rng.integers(0, 3) == 0:
+        env["IRB_OFFLINE_DIRECT"] = "1"                  # the opt-in registered form; otherwise the default (staged) form
     os.environ.update(env)
     x = np.stack([white_noise(int(rng.integers(1 << 30)), La) for _ in range(Ca)])
     h = np.stack([decaying_ir(int(rng.integers(1 << 30)), Lh) for _ in range(Ci)])

@@ -9,15 +9,13 @@ from irbaboon_amd.synth import decaying_ir, white_noise
 B, Lh, I, C, steps, chunk = 64, 1000, 6, 2, 20000, 500
 x = np.stack([white_noise(1 + s, steps * B) for s in range(I * C)])
 irs = [np.stack([decaying_ir(50 + 2 * i + c, Lh) for c in range(C if i % 2 else 1)]) for i in range(I)]
-paths = [("fused(+pair)", _lib.FORCE_FUSED, 1, None), ("split 1-launch", _lib.FORCE_SPLIT, 1, None),
-         ("split 3-launch", _lib.FORCE_SPLIT | _lib.SPLIT_3LAUNCH, 1, None), ("tiled", 0, 7, None), ("tiled mfma", 0, 500, None),
-         ("cols ticket", _lib.FORCE_COLS, 1, "0"), ("cols fences", _lib.FORCE_COLS, 1, "1"), ("cols granules", _lib.FORCE_COLS, 1, "2")]
+paths = [("fused(+pair)", _lib.FORCE_FUSED, 1, None), ("tiled", 0, 7, None), ("tiled mfma", 0, 500, None),
+         ("cols ticket", _lib.FORCE_COLS, 1, "0"), ("cols granules", _lib.FORCE_COLS, 1, "2")]
 for name, flags, tmax, handoff in paths:
-    if handoff is None:
-        os.environ.pop("IRB_COLS_HANDOFF", None)
-    else:
-        os.environ["IRB_COLS_HANDOFF"] = handoff        # read when the engine is created
-    os.environ["IRB_TILED_MFMA_MIN_T"] = "256" if name == "tiled mfma" else "0"       # calls of 500 blocks on the matrix cores / never
+    dbg = ["mfma_min_t=" + ("256" if name == "tiled mfma" else "0")]       # calls of 500 blocks on the matrix cores / never
+    if handoff is not None:
+        dbg.append("cols_handoff=" + handoff)                               # read when the engine is created
+    os.environ["IRB_DEBUG"] = ",".join(dbg)
     t0 = time.time()
     with FdlEngine(I, C, B, Lh, max_blocks_per_call=tmax, flags=flags) as eng:
         for i in range(I):

@@ -1,7 +1,9 @@
-"""Second form of the stale-page probe: every call has its own random lengths (stereo, B = 256), large float64 temporaries are
+"""The stale-page probe (round 4's first form -- identical content every repeat -- could not see a stale page that still held the previous
+repeat's bytes and was removed): every call has its own random lengths (stereo, B = 256), large float64 temporaries are
 allocated and freed between calls (what scipy's reference convolution does in tools/fuzz_paths.py: mmap / munmap churn), and the
-DIRECT form's result is compared bit for bit with the STAGED form's (IRB_OFFLINE_DIRECT is read per call; same kernels, the
-samples travel through the library's pinned memory instead of the registered caller memory).
+opt-in REGISTERED form's result (IRB_OFFLINE_DIRECT=1) is compared bit for bit with the default STAGED form's (read per call; same
+kernels, the samples travel through the library's pinned memory instead of the registered caller memory).  Not run in round 5
+(no more GPU minutes on reproducing the event; the registered form is no longer a default).
 usage: python tools/stale_page_probe2.py [seconds] [seed]"""
 import os
 import sys
@@ -16,7 +18,7 @@ from irbaboon_amd.synth import decaying_ir, white_noise
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-os.environ.update({"IRB_TILED_MFMA_MIN_T": "2", "IRB_TILED_MFMA_WGS": "2048", "IRB_TILED_MFMA_MIN_CHUNKS": "1"})
+os.environ["IRB_DEBUG"] = "mfma_min_t=2,mfma_wgs=2048,mfma_min_chunks=1"
 lib = _lib.lib()
 B = 256
 noise = [white_noise(100 + k, 80000) for k in range(8)]
@@ -28,8 +30,11 @@ while time.time() < t_end:
     x = np.stack([noise[int(rng.integers(8))][:La], noise[int(rng.integers(8))][:La]])
     h = np.stack([irs[int(rng.integers(8))][:Lh], irs[int(rng.integers(8))][:Lh]])
     res = []
-    for direct in ("1", "0"):
-        os.environ["IRB_OFFLINE_DIRECT"] = direct
+    for direct in ("1", None):
+        if direct:
+            os.environ["IRB_OFFLINE_DIRECT"] = direct
+        else:
+            os.environ.pop("IRB_OFFLINE_DIRECT", None)
         out = np.full((2, La + Lh - 1), 1e30, np.float32)
         assert lib.irb_convolve_periodic(0, planar_ptrs(x), 2, La, planar_ptrs(h), 2, Lh, B, 1, planar_ptrs(out)) == 0
         res.append(out)

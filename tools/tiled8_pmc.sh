@@ -8,7 +8,7 @@ R=/root/repo
 TAG=${1:-base}
 O=$R/gpurun_out/tiled8_pmc_$TAG
 rm -rf $O; mkdir -p $O
-ARGS="256 96000 8 2048 10"   # (IRB_TILED_FUSED8=0 in the environment: the three-launch form)
+ARGS="256 96000 8 2048 10"   # (IRB_DEBUG=tiled_fused8=0 in the environment: the three-launch form)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/tools/perf_probe.py offline $ARGS > $O/kt.log 2>&1 || exit 1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE"; do
