@@ -229,7 +229,18 @@ def other_configs(dev, np, FdlEngine, decaying_ir, white_noise):
             flops = 8.0 * e.info.partitions * (e.info.fft_len // 2) * T * I * C
             ent["fp32_flops"] = flops
             ent["TFLOPs"] = round(flops / ms / 1e9, 2)
-            ent["frac_of_157.3"] = round(flops / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
+            # two bases, both against the 157.3 TFLOP/s fp32 peak and both over the WHOLE call (forward FFTs + MAC + inverse FFTs):
+            #   algorithmic: the reference's arithmetic, 8 flop per complex bin, partition and block (four real products + four adds)
+            #   executed:    what k_cmac_mfma issues -- THREE real products per complex one (two for the packed bin 0) on whole 256-block tiles and
+            #                whole 16-tap chunks: tiles * chunks * (12 (M - 1) + 8) v_mfma_f32_16x16x4_f32 of 2048 flop each (= SQ_INSTS_MFMA x 2048,
+            #                profiles/r04_mfma_pmc.txt: 1 150 500 instructions at configs[1])
+            ent["frac_algorithmic_4product"] = round(flops / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
+            if e.mac_kernel_name(T) == "k_cmac_mfma":
+                M, P = e.info.fft_len // 2, e.info.partitions
+                chunks = (P + 14) // 16 + 1
+                executed = float(I * C) * ((T + 255) // 256) * chunks * (12 * (M - 1) + 8) * 2048.0
+                ent["executed_mfma_flops"] = executed
+                ent["frac_executed_mfma"] = round(executed / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS, 4)
             # the least a call must move: every H row and every row of the FDL window (P past blocks + the call's T) once, fp32
             min_bytes = float(I * C) * (2 * e.info.partitions + T) * e.info.fft_len * 4.0
             ent["min_traffic_GBps"] = round(min_bytes / ms / 1e6, 1)

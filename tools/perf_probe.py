@@ -16,13 +16,15 @@ def timed(eng, d_in, d_out, stride, T, reps):
     return eng.elapsed_ms() / reps
 
 
-def offline(B=256, Lh=96000, T=3750, S=1, reps=5):
-    """one call carrying T blocks per stream (time-tiled path)"""
+def offline(B=256, Lh=96000, T=3750, S=1, reps=5, same_data=0):
+    """one call carrying T blocks per stream (time-tiled path); same_data=1: one IR and one signal for every stream (counter runs: the
+    traffic is the same, the set-up of 2048 streams is not)"""
     eng = FdlEngine(S, 1, B, Lh, max_blocks_per_call=T)
+    h0, x0 = decaying_ir(1, Lh), white_noise(5, T * B)
     for i in range(S):
-        eng.set_ir(i, decaying_ir(1 + i, Lh))
+        eng.set_ir(i, h0 if same_data else decaying_ir(1 + i, Lh))
     d_in, d_out, stride = eng.device_io()
-    eng.upload(d_in, np.stack([white_noise(5 + i, T * B) for i in range(S)]))
+    eng.upload(d_in, np.stack([x0 if same_data else white_noise(5 + i, T * B) for i in range(S)]))
     if reps > 50:
         timed(eng, d_in, d_out, stride, T, reps)        # sustained load first: the clock the chip settles at
     ms = timed(eng, d_in, d_out, stride, T, reps)
