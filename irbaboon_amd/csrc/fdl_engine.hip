@@ -97,11 +97,6 @@ struct irb_fdl {
     bool mfma_capable = false;               // this handle's longest call multiplies on the matrix cores: d_Xt / d_Ht exist
     float2 *d_Xt = nullptr, *d_Ht = nullptr; // [S][M][xt_len], [S][M][ht_len]
     int xt_len = 0, xt_hist = 0, ht_len = 0;
-    // ... and its one-grid form (k_long_call, fdl_longcall.hpp): hand-off words, the number of the last call that used them
-    bool long_call = false;                  // N <= 512; IRB_DEBUG=long_call=0: the three launches (tools that trace the kernels apart, A/B)
-    unsigned *d_lc = nullptr;
-    size_t lc_words = 0;
-    unsigned lc_seq = 0;
     float2 *d_H = nullptr, *d_X = nullptr, *d_tw = nullptr, *d_part = nullptr;
     float *d_ovl = nullptr, *d_in = nullptr, *d_out = nullptr, *d_irtime = nullptr;
     int2 *d_stream_info = nullptr;          // [S] {IR set, partitions in use}: what the kernels read
@@ -313,7 +308,6 @@ irb::StepArgs step_args(const irb_fdl *h, const float *d_in, float *d_out, long 
     a.rf_src = nullptr; a.rf_part = 0; a.done = nullptr; a.done_seq = 0; a.debug_drop = 0;
     a.ck_cnt = nullptr; a.ck_flag = nullptr; a.ck_blocks = 1; a.ck_seq = 0;
     a.pk_flag = nullptr; a.pk_blocks = 16; a.pk_seq = 0; a.dbg_sums = nullptr;
-    a.lc_flags = h->d_lc; a.lc_seq = 0; a.lc_nA = 0; a.lc_nB = 0;
     a.stream_info = h->d_stream_info;
     a.in = d_in; a.out = d_out; a.part = h->d_part;
     a.in_stride = stride; a.out_stride = stride;
@@ -445,25 +439,6 @@ int tiled_push(irb_fdl *h, const TiledCall &c, int first, int count, hipStream_t
     return IRB_OK;
 }
 
-// the plan of a matrix-core call in the kernel's arguments; returns the multiply's workgroups.  Both regions of a two-region plan go
-// into ONE grid: the second's workgroups (few, short) come last in dispatch order and run on the CUs the first round frees
-int mfma_args(const irb_fdl *h, const TiledCall &c, irb::StepArgs *a)
-{
-    const int groups = h->M / irb::kMfmaBins;
-    auto wgs = [&](const MfmaLaunch &l) { return h->S * l.tile_count * l.splits * groups; };
-    const MfmaLaunch &l0 = c.plan.l[0];
-    float2 *const part0 = a->part;
-    a->tile_first = l0.tile_first; a->tile_count = l0.tile_count; a->splits = l0.splits; a->nq = l0.splits;
-    a->t_base = a->reg_t0[0]; a->part_T = a->reg_t0[1] - a->reg_t0[0]; a->part = part0 + a->reg_off[0];     // (reg_off[0] = 0)
-    a->mf_wgs0 = 0;
-    if (c.plan.n < 2) return wgs(l0);
-    const MfmaLaunch &l1 = c.plan.l[1];
-    a->mf_wgs0 = wgs(l0);
-    a->mf2_tile_first = l1.tile_first; a->mf2_tile_count = l1.tile_count; a->mf2_splits = l1.splits;
-    a->mf2_t_base = a->reg_t0[1]; a->mf2_part_T = a->reg_t0[2] - a->reg_t0[1]; a->mf2_part_off = (long) a->reg_off[1] - (long) a->reg_off[0];
-    return wgs(l0) + wgs(l1);
-}
-
 int tiled_mac(irb_fdl *h, const TiledCall &c)
 {
     irb::StepArgs a = c.a;
@@ -472,8 +447,29 @@ int tiled_mac(irb_fdl *h, const TiledCall &c)
     const bool nt1 = h->nt && c.ntiles == 1;
     h->n_launches++;
     if (c.mfma) {
-        const int wgs = mfma_args(h, c, &a);
-        FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        const int groups = h->M / irb::kMfmaBins;
+        float2 *const part0 = a.part;
+        h->n_launches--;
+        auto wgs = [&](const MfmaLaunch &l) { return h->S * l.tile_count * l.splits * groups; };
+        if (c.plan.n == 2) {
+            // both regions of the plan in ONE grid: the second's workgroups (few, short) come last in dispatch order and run on
+            // the CUs the first round frees -- one launch's fixed cost instead of two
+            const MfmaLaunch &l0 = c.plan.l[0], &l1 = c.plan.l[1];
+            h->n_launches++;
+            a.tile_first = l0.tile_first; a.tile_count = l0.tile_count; a.splits = l0.splits; a.nq = l0.splits;
+            a.t_base = a.reg_t0[0]; a.part_T = a.reg_t0[1] - a.reg_t0[0]; a.part = part0 + a.reg_off[0];
+            a.mf_wgs0 = wgs(l0);
+            a.mf2_tile_first = l1.tile_first; a.mf2_tile_count = l1.tile_count; a.mf2_splits = l1.splits;
+            a.mf2_t_base = a.reg_t0[1]; a.mf2_part_T = a.reg_t0[2] - a.reg_t0[1]; a.mf2_part_off = (long) a.reg_off[1] - (long) a.reg_off[0];
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l0) + wgs(l1)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        } else {
+            const MfmaLaunch &l = c.plan.l[0];
+            h->n_launches++;
+            a.tile_first = l.tile_first; a.tile_count = l.tile_count; a.splits = l.splits; a.nq = l.splits;
+            a.t_base = a.reg_t0[0]; a.part_T = a.reg_t0[1] - a.reg_t0[0]; a.part = part0 + a.reg_off[0];
+            a.mf_wgs0 = 0;
+            FOR_N(h->N, irb::k_cmac_mfma<NN><<<dim3(wgs(l)), dim3(irb::kMfmaThreads), 0, h->stream>>>(a));
+        }
     }
     else if (c.one_bin) { FOR_N(h->N, irb::k_cmac_tiled1<NN, 16><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
     else if (c.tt == 8 && nt1) { FOR_N(h->N, irb::k_cmac_tiled_pk<NN, 8, 4, 4, true><<<mac_grid, mac_block, 0, h->stream>>>(a)); }
@@ -522,33 +518,6 @@ int launch_tiled(irb_fdl *h, irb::StepArgs a, int T)
     }
     TiledCall c;
     int rc = tiled_begin(h, a, T, &c);
-    if (rc == IRB_OK && c.mfma && h->long_call) {
-        // forward FFTs, multiply, inverse FFTs as regions of ONE grid (k_long_call)
-        irb::StepArgs f = c.a;
-        f.t_first = 0; f.t_count = T;
-        const int groups = (T + 15) / 16, hist_wgs = f.hist_first >= 0 ? h->S * (h->xt_hist / 16) * std::max(1, h->M / 64) : 0;
-        f.lc_nA = h->S * groups + hist_wgs;
-        f.lc_nB = mfma_args(h, c, &f);
-        const int nC = h->S * ((T + irb::kLcOlaBlocks - 1) / irb::kLcOlaBlocks);
-        if ((size_t) f.lc_nA + f.lc_nB > h->lc_words) return fail(IRB_ERR_STATE, "hand-off words too few (internal)");
-        if (++h->lc_seq == 0) {                           // the numbers wrapped: no word may still hold one that comes again
-            HIP_TRY(hipMemsetAsync(h->d_lc, 0, sizeof(unsigned) * h->lc_words, h->stream));
-            h->lc_seq = 1;
-        }
-        f.lc_seq = h->lc_seq;
-        h->n_launches++;
-        switch (h->N) {
-        case 32:  irb::k_long_call<32><<<dim3(f.lc_nA + f.lc_nB + nC), dim3(irb::kMfmaThreads), 0, h->stream>>>(f, h->S); break;
-        case 64:  irb::k_long_call<64><<<dim3(f.lc_nA + f.lc_nB + nC), dim3(irb::kMfmaThreads), 0, h->stream>>>(f, h->S); break;
-        case 128: irb::k_long_call<128><<<dim3(f.lc_nA + f.lc_nB + nC), dim3(irb::kMfmaThreads), 0, h->stream>>>(f, h->S); break;
-        case 256: irb::k_long_call<256><<<dim3(f.lc_nA + f.lc_nB + nC), dim3(irb::kMfmaThreads), 0, h->stream>>>(f, h->S); break;
-        case 512: irb::k_long_call<512><<<dim3(f.lc_nA + f.lc_nB + nC), dim3(irb::kMfmaThreads), 0, h->stream>>>(f, h->S); break;
-        default: return fail(IRB_ERR_STATE, "one-grid long call: FFT length %d (internal)", h->N);
-        }
-        HIP_TRY(hipGetLastError());
-        h->ovl_cur ^= 1;
-        return IRB_OK;
-    }
     if (rc == IRB_OK) rc = tiled_push(h, c, 0, T);
     if (rc == IRB_OK) rc = tiled_mac(h, c);
     if (rc == IRB_OK) rc = tiled_ifft(h, c, 0, T);
@@ -991,7 +960,7 @@ void irb_fdl_destroy(irb_fdl *h)
     if (h->stream) (void) irb_sync(h);
     DeviceQuiet quiet(h->device);                        // the frees below wait for every stream of the device: other instances' servers step aside
     (void) hipFree(h->d_H); (void) hipFree(h->d_X); (void) hipFree(h->d_tw); (void) hipFree(h->d_part);
-    (void) hipFree(h->d_Xt); (void) hipFree(h->d_Ht); (void) hipFree(h->d_lc);
+    (void) hipFree(h->d_Xt); (void) hipFree(h->d_Ht);
     (void) hipFree(h->d_ovl); (void) hipFree(h->d_in); (void) hipFree(h->d_out); (void) hipFree(h->d_irtime);
     (void) hipFree(h->d_stream_info); (void) hipFree(h->d_tickets); (void) hipFree(h->d_gran);
     if (h->h_status) (void) hipHostFree(h->h_status);
@@ -1088,23 +1057,6 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             h->part_rows = rows;
         }
         if (!guard(dev_alloc(h, &h->d_part, h->part_rows * h->M))) break;
-        // the one-grid form of matrix-core calls: one word per forward-FFT workgroup (history workgroups included) and per multiply
-        // workgroup of the longest plan; buffer offsets inside one stream's Xt rows / partial spectra are 32-bit
-        h->long_call = h->mfma_capable && h->N <= 512 && dbg_int("long_call", 1) != 0 &&
-                       (size_t) h->M * h->xt_len * sizeof(float2) < ((size_t) 1 << 31);
-        if (h->long_call) {
-            const int groups_max = (h->Tmax + 15) / 16, hist_wgs = (h->xt_hist / 16) * std::max(1, h->M / 64), bin_groups = h->M / irb::kMfmaBins;
-            size_t mac_max = 0;
-            for (int T = 2; T <= h->Tmax; T++) {
-                if (!use_mfma(h, T)) continue;
-                const MfmaPlan p = mfma_plan(h, T);
-                size_t w = 0;
-                for (int i = 0; i < p.n; i++) w += (size_t) h->S * p.l[i].tile_count * p.l[i].splits * bin_groups;
-                mac_max = std::max(mac_max, w);
-            }
-            h->lc_words = (size_t) h->S * (groups_max + hist_wgs) + mac_max;
-            if (!guard(dev_alloc(h, &h->d_lc, h->lc_words))) break;
-        }
         if (!guard(dev_alloc(h, &h->d_ovl, (size_t) 2 * h->S * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_in, (size_t) h->S * h->Tmax * h->B))) break;
         if (!guard(dev_alloc(h, &h->d_out, (size_t) h->S * h->Tmax * h->B))) break;
@@ -1186,7 +1138,6 @@ int irb_fdl_create(const irb_fdl_config *cfg, irb_fdl **out)
             (e = hipMemsetAsync(h->d_X, 0, sizeof(float2) * SM * h->R, h->stream)) != hipSuccess ||
             (h->d_Xt && (e = hipMemsetAsync(h->d_Xt, 0, sizeof(float2) * SM * h->xt_len, h->stream)) != hipSuccess) ||
             (h->d_Ht && (e = hipMemsetAsync(h->d_Ht, 0, sizeof(float2) * SM * h->ht_len, h->stream)) != hipSuccess) ||
-            (h->d_lc && (e = hipMemsetAsync(h->d_lc, 0, sizeof(unsigned) * h->lc_words, h->stream)) != hipSuccess) ||
             (e = hipMemsetAsync(h->d_ovl, 0, sizeof(float) * (size_t) 2 * h->S * h->B, h->stream)) != hipSuccess ||
             (e = hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * (size_t) h->S, h->stream)) != hipSuccess ||
             (h->d_gran && (e = hipMemsetAsync(h->d_gran, 0, sizeof(unsigned long long) * (size_t) h->S * h->splits * h->N, h->stream)) != hipSuccess) ||

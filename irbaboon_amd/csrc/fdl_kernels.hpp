@@ -100,12 +100,6 @@ struct StepArgs {
     // every block's samples AS THEY READ THEM at dbg_sums[s * T + j] -- what a wrong result is compared with first (did the device see
     // the bytes the host sees?)
     unsigned     *dbg_sums;
-    // k_long_call (fdl_longcall.hpp): forward FFTs, multiply and inverse FFTs of a long call as regions of ONE grid -- the hand-off
-    // words (one per forward-FFT workgroup [0, lc_nA), then one per multiply workgroup), this call's number (never 0, never
-    // repeated within a handle), the workgroups of the first two regions
-    unsigned     *lc_flags;
-    unsigned      lc_seq;
-    int           lc_nA, lc_nB;
 };
 
 #ifdef IRB_STAMPS
@@ -119,10 +113,10 @@ __device__ __forceinline__ void stamp_(unsigned long long *buf, int i)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + i] = t;
-    if (i == 0 || i == 1 || i == 7 || i == 10) {     // the 100 MHz reference clock too: comparable ACROSS workgroups / XCDs
+    if (i == 0 || i == 7 || i == 10) {               // the 100 MHz reference clock too: comparable ACROSS workgroups / XCDs
         unsigned long long r;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) :: "memory");
-        if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + (i == 0 ? 11 : i == 1 ? 8 : i == 7 ? 12 : 13)] = r;
+        if (threadIdx.x == 0) buf[(size_t) blockIdx.x * 16 + (i == 0 ? 11 : i == 7 ? 12 : 13)] = r;
     }
 }
 #endif
@@ -994,15 +988,12 @@ __global__ __launch_bounds__(kThreads) void k_cmac_tiled1(StepArgs a)
     }
 }
 
-// one wave: sum the nq partial rows of one output block into buf (LDS).  SC1: the rows were written by workgroups of the same
-// launch (k_long_call) -- every load of them is an sc1 buffer load; `src` is wave-uniform
-template <int N, bool SC1 = false>
+// one wave: sum the nq partial rows of one output block into buf (LDS)
+template <int N>
 __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, int nq, float2 *buf, int lane)
 {
     constexpr int M = N / 2, L = M / 2, CPL = L >= kWave ? L / kWave : 1;
     const float4 *src4 = reinterpret_cast<const float4 *>(src);
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(src), 0, SC1 ? nq * M * 8 : 0, 0x00020000);
     float4 v[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1014,10 +1005,7 @@ __device__ __forceinline__ void wave_sum_rows(const float2 *__restrict__ src, in
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-                if constexpr (SC1) {
-                    const u4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned) ((min(q0 + i, nq - 1) * L + min(lane + c * kWave, L - 1)) * 16), 0, 16 /* sc1 */);
-                    w[i][c] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
-                } else w[i][c] = src4[(size_t) min(q0 + i, nq - 1) * L + min(lane + c * kWave, L - 1)];
+                w[i][c] = src4[(size_t) min(q0 + i, nq - 1) * L + min(lane + c * kWave, L - 1)];
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (q0 + i < nq) {
@@ -1143,5 +1131,4 @@ __global__ __launch_bounds__(kWave * FftGeom<N>::NF) void k_ir_fft_direct(IrDire
 
 #include "fdl_tiled_pk.hpp"
 #include "fdl_mfma.hpp"
-#include "fdl_longcall.hpp"
 #include "fdl_rt_kernel.hpp"

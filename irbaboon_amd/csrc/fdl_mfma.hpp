@@ -45,8 +45,6 @@
 namespace irb {
 
 typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaSeg = 16;                           // segment length = MFMA tile edge
 constexpr int kMfmaTile = kMfmaSeg * kMfmaSeg;         // output blocks per workgroup tile
@@ -74,54 +72,6 @@ __device__ __forceinline__ void nt_store2(float2 *dst, float2 v)
 {
     v2f_t q = {v.x, v.y};
     __builtin_nontemporal_store(q, reinterpret_cast<v2f_t *>(dst));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Hand-off words of the one-grid long call (k_long_call, fdl_longcall.hpp): forward FFTs, multiply and inverse FFTs of a call are
-// regions of ONE grid, in dispatch order, and a workgroup of a later region waits for the workgroups of the earlier region whose bytes
-// it reads.  The form is the one k_step_cols' hand-off 0 uses (MI355X_MICROARCH.md, "Valid forms", first row of the table of
-// measured hand-offs; not an architectural guarantee -- the library is built for gfx950 only):
-//   producer   every handed-off byte stored write-through (sc1; 8 or 16 bytes per lane), every storing wave drains (vmcnt(0)),
-//              workgroup barrier, ONE lane stores the call's number into the workgroup's own word (sc1)
-//   consumer   wave 0 polls the words of the producers it depends on (sc1 loads, one word per lane and round) until all hold the
-//              call's number, workgroup barrier, then EVERY load of handed-off bytes is an sc1 load to registers (they bypass the
-//              CU's L1; no line of those bytes was touched by this launch before its last store was acknowledged: the waits below
-//              cover everything a workgroup ADDRESSES, the matrix kernel's run-ahead loads included)
-// No release / acquire fence (~1.7 us each, per CU and hop), no atomics (235 arrivals on one counter = ~3 us), no reset between
-// calls: a word holds the number of the last call that published it, numbers never repeat within a handle.  One workgroup per CU
-// (1024 threads, > 64 VGPRs).  No co-residency assumption: a consumer only waits for workgroups of LOWER index, which the
-// dispatcher started before it; the polls are bounded all the same (1 s of the 100 MHz clock -> StepArgs::status, wrong output,
-// IRB_ERR_STATE at the host's next wait) so that no grid can be left behind.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lc_publish(const StepArgs &a, int word)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores are acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(a.lc_flags + word, a.lc_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// words [f0, f0 + n0) and [f1, f1 + n1) (either range may be empty)
-__device__ __forceinline__ void lc_wait(const StepArgs &a, int f0, int n0, int f1, int n1)
-{
-    if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x;
-        unsigned long long t0, t1;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
-        for (;;) {
-            bool ok = true;
-            for (int i = lane; i < n0; i += kWave) ok = ok && __hip_atomic_load(a.lc_flags + f0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.lc_seq;
-            for (int i = lane; i < n1; i += kWave) ok = ok && __hip_atomic_load(a.lc_flags + f1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.lc_seq;
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(2);
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
-            if (t1 - t0 > 100000000ull) {
-                if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the compiler from moving loads above the wait)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,23 +116,21 @@ __global__ __launch_bounds__(256) void k_rows_to_columns(const float2 *__restric
 // ---------------------------------------------------------------------------------------------
 template <int N> struct PushTGeom { static constexpr int NBW = N <= 512 ? 16 : N == 1024 ? 8 : N == 2048 ? 4 : 2; };
 
-// FUSED: the workgroup is part of k_long_call's grid (fdl_longcall.hpp) -- its Xt columns are read by multiply workgroups of the
-// SAME launch, so they are stored write-through (sc1, 16 bytes per lane), drained, and the workgroup's word published (lc_publish).
-template <int N, bool FUSED>
-__device__ __forceinline__ void push_fft_batch_t_body(const StepArgs &a, int S, int bid, float2 *l_tw, float2 (*l_buf)[N / 2 + 1])
+template <int N>
+__global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(StepArgs a, int S)
 {
     constexpr int M = N / 2, NBW = PushTGeom<N>::NBW;
-    static_assert(!FUSED || NBW == kMfmaSeg, "the one-grid form hands whole segments of 16 blocks over");
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[NBW][M + 1];               // (+1: the transposed read below walks the block index at a fixed bin)
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int groups = (a.t_count + NBW - 1) / NBW;
-    IRB_STAMP(a, 0);
-    if (bid >= S * groups) {
+    if ((int) blockIdx.x >= S * groups) {
         // extra workgroups of a call that continues a stream (a.hist_first >= 0): the xt_hist blocks before the call's first one go
         // from the FDL ring into Xt's history columns (k_rows_to_columns' transpose, plus the segment permutation), 16 ring
         // rows x 64 bins per workgroup through LDS
         constexpr int BW = M < 64 ? M : 64, BY = M / BW;
         float2 (*l_t)[BW + 1] = reinterpret_cast<float2 (*)[BW + 1]>(&l_buf[0][0]);
-        const int w = bid - S * groups, r0 = (w % (a.xt_hist / 16)) * 16, b0 = ((w / (a.xt_hist / 16)) % BY) * BW, s = w / ((a.xt_hist / 16) * BY);
+        const int w = blockIdx.x - S * groups, r0 = (w % (a.xt_hist / 16)) * 16, b0 = ((w / (a.xt_hist / 16)) % BY) * BW, s = w / ((a.xt_hist / 16) * BY);
         const float2 *src = a.X + (size_t) s * a.R * M;
         float2 *dst = a.Xt + (size_t) s * M * a.xt_len;
         for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
@@ -192,14 +140,11 @@ __device__ __forceinline__ void push_fft_batch_t_body(const StepArgs &a, int S, 
         __syncthreads();
         for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
             const int b = e / 16, q = e % 16, c = (q >> 1) & 1, t = mfma_xt_slot_block(q);
-            const float2 v = make_float2(mfma_component(l_t[t][b], c), mfma_component(l_t[t + 4][b], c));
-            if constexpr (FUSED) st_sc1(dst + (size_t) (b0 + b) * a.xt_len + r0 + q, v);
-            else dst[(size_t) (b0 + b) * a.xt_len + r0 + q] = v;
+            dst[(size_t) (b0 + b) * a.xt_len + r0 + q] = make_float2(mfma_component(l_t[t][b], c), mfma_component(l_t[t + 4][b], c));
         }
-        if constexpr (FUSED) { lc_publish(a, bid); IRB_STAMP(a, 7); }
         return;
     }
-    const int s = bid / groups, j0 = a.t_first + (bid % groups) * NBW;
+    const int s = blockIdx.x / groups, j0 = a.t_first + (blockIdx.x % groups) * NBW;
     const int j = j0 + wave;
     const bool live = j < a.t_first + a.t_count;
     TwiddleStage<N, kWave * NBW> tws;
@@ -243,21 +188,6 @@ __device__ __forceinline__ void push_fft_batch_t_body(const StepArgs &a, int S, 
     // streaming handle after a burst -- the reference's calls are independent).
     float2 *xt = a.Xt + (size_t) s * M * a.xt_len + a.xt_hist;
     const int t_end = a.t_first + a.t_count;
-    if constexpr (FUSED) {
-        // 16 bytes per lane: the slots 2 q and 2 q + 1 of a segment = component q & 1 of the blocks (q >> 1) + {0, 4, 8, 12}
-        for (int e = threadIdx.x; e < M * (NBW / 2); e += kWave * NBW) {
-            const int bin = e / (NBW / 2), q = e % (NBW / 2), c = q & 1, t = q >> 1;
-            v4f_t v;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = j0 + t + 4 * k < t_end ? mfma_component(l_buf[t + 4 * k][bin], c) : 0.f;
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(xt, 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), r, (unsigned) (((size_t) bin * a.xt_len + j0 + 2 * q) * 8), 0, 16 /* sc1 */);
-        }
-        IRB_STAMP(a, 1);
-        lc_publish(a, bid);
-        IRB_STAMP(a, 7);
-        return;
-    }
     for (int e = threadIdx.x; e < M * NBW; e += kWave * NBW) {
         const int bin = e / NBW, p = e % NBW;
         if constexpr (NBW == kMfmaSeg) {               // the workgroup holds a whole segment: slot p takes one component of two of its blocks
@@ -284,19 +214,12 @@ __device__ __forceinline__ void push_fft_batch_t_body(const StepArgs &a, int S, 
             }
         }
     }
-    IRB_STAMP(a, 7);
-}
-
-template <int N>
-__global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(StepArgs a, int S)
-{
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[PushTGeom<N>::NBW][N / 2 + 1];         // (+1: the transposed read walks the block index at a fixed bin)
-    push_fft_batch_t_body<N, false>(a, S, (int) blockIdx.x, l_tw, l_buf);
 }
 
 // buffer loads: per-lane byte offset in a VGPR, row step in an SGPR, a constant in the immediate; everything the kernel addresses
 // exists in the padded layouts
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 template <int IMM>
 __device__ __forceinline__ float2 buf_ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
@@ -342,8 +265,7 @@ __device__ __forceinline__ float2 from_lane(int byte_addr, float2 v)
 // The lanes that have nothing to load carry a byte offset beyond the buffer (the descriptor's range check returns zeros without a
 // memory access): no exec-mask branches in the loop.  Every non-MFMA instruction takes matrix-pipe time from the other three waves
 // of the SIMD (ablation in profiles/NOTES.md), so the loop is exactly 12 MFMAs + 8 ds_bpermute + 8 DPP moves + 4 packed adds + 3 loads.
-// XAUX: cache-policy bits of the loads of Xt (0; 16 = sc1 where the columns were written by workgroups of the same launch)
-template <bool PACKED, int XAUX>
+template <bool PACKED>
 __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rh, int lane, int x_elem0, int jb, int je,
                                                v4f_t &acc_r, v4f_t &acc_n, v4f_t &acc_i, const StepArgs &a)
 {
@@ -363,7 +285,7 @@ __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdg
     Set A, B;
     auto load_taps = [&](Set &s, int j) { s.taps = buf_ld8<0>(rh, vh, sh(j)); };
     auto load_x = [&](Set &s, unsigned v, int j) {                         // (a chunk past the range reads blocks / taps that exist in the padded layouts: never used)
-        const v4u_t re = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j), XAUX), im = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j) + 16, XAUX);
+        const v4u_t re = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j), 0), im = __builtin_amdgcn_raw_buffer_load_b128(rx, v, sx(j) + 16, 0);
 #pragma unroll
         for (int g = 0; g < 4; g++) { s.xr[g] = __uint_as_float(re[g]); s.xi[g] = __uint_as_float(im[g]); }
     };
@@ -432,25 +354,22 @@ __device__ __forceinline__ void mfma_chunk_run(__amdgpu_buffer_rsrc_t rx, __amdg
 // grid = S * tile_count * splits * (M / 16); block = 1024.  Partial spectra: part[s][t - t_base][split][M], part_T blocks per
 // stream (a call may be multiplied in two launches -- whole rounds of workgroups, then the remaining tiles with more partition
 // splits -- each with its own partial-spectrum region; see launch_tiled).
-// bid / nwg: the workgroup's index among, and the number of, the multiply workgroups of the launch.
-// FUSED: part of k_long_call's grid (fdl_longcall.hpp) -- waits for the forward-FFT workgroups whose Xt columns it addresses, loads
-// Xt with sc1, stores its partial spectra write-through (16 bytes per lane) and publishes its word (index: lc_nA + its place in the
-// plan's decode order, so that the words of one tile's workgroups are contiguous).
-template <int N, bool FUSED>
-__device__ __forceinline__ void cmac_mfma_body(const StepArgs &a, int S, int bid, int nwg, float2 *l_o)
+template <int N>
+__global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
 {
     constexpr int M = N / 2;
     static_assert(M % kMfmaBins == 0, "bins per workgroup");
     constexpr int GROUPS = M / kMfmaBins;
+    __shared__ float2 l_o[kMfmaTile * kMfmaOS];
     // one grid may carry both launches of a call's plan (whole rounds of workgroups, then the remaining tiles with their partitions
     // split): the second region's workgroups are the LAST in dispatch order, short, and start as the first region's CUs free up
-    const bool second = a.mf_wgs0 > 0 && bid >= a.mf_wgs0;
+    const bool second = a.mf_wgs0 > 0 && (int) blockIdx.x >= a.mf_wgs0;
     const int tile_first = second ? a.mf2_tile_first : a.tile_first, tile_count = second ? a.mf2_tile_count : a.tile_count,
               splits = second ? a.mf2_splits : a.splits, t_base = second ? a.mf2_t_base : a.t_base, part_T = second ? a.mf2_part_T : a.part_T;
     float2 *const part = second ? a.part + a.mf2_part_off : a.part;
-    const int first_wgs = a.mf_wgs0 > 0 ? min(a.mf_wgs0, nwg) : nwg;
+    const int first_wgs = a.mf_wgs0 > 0 ? min(a.mf_wgs0, (int) gridDim.x) : (int) gridDim.x;
     // the bin groups and splits of one tile share an XCD's L2 (the same FDL lines)
-    const int wg = second ? xcd_contiguous_id(bid - a.mf_wgs0, nwg - a.mf_wgs0) : xcd_contiguous_id(bid, first_wgs);
+    const int wg = second ? xcd_contiguous_id(blockIdx.x - a.mf_wgs0, gridDim.x - a.mf_wgs0) : xcd_contiguous_id(blockIdx.x, first_wgs);
     const int bg = wg % GROUPS, split = (wg / GROUPS) % splits, tile = tile_first + (wg / (GROUPS * splits)) % tile_count,
               s = wg / (GROUPS * splits * tile_count);
     const int2 si = a.stream_info[s];
@@ -473,21 +392,10 @@ __device__ __forceinline__ void cmac_mfma_body(const StepArgs &a, int S, int bid
 #pragma unroll
     for (int v = 0; v < 4; v++) { acc_r[v] = 0.f; acc_n[v] = 0.f; acc_i[v] = 0.f; }
     const int x_elem0 = a.xt_hist + kMfmaTile * tile;              // Xt element of the tile's first block
-    if constexpr (FUSED) {
-        // what this workgroup ADDRESSES in Xt: the segments 16 tile - j + n, n < 16, of the chunks j in [jb, je + 3) (three chunks of
-        // loads run ahead of the last product) -- forward-FFT workgroups g (= segments of the call) in [16 tile - je - 2, 16 tile - jb + 16),
-        // and, where that reaches in front of the call's first block, the workgroups that rebuild the history columns
-        if (jb < je) {
-            const int groups = (a.t_count + kMfmaSeg - 1) / kMfmaSeg;
-            const int g_lo = kMfmaSeg * tile - je - 2, g0 = max(g_lo, 0), g1 = min(kMfmaSeg * tile - jb + kMfmaSeg, groups);
-            const int hist_wgs = (a.xt_hist / 16) * (M < 64 ? 1 : M / 64);
-            lc_wait(a, s * groups + g0, g1 - g0, S * groups + s * hist_wgs, g_lo < 0 && a.hist_first >= 0 ? hist_wgs : 0);
-        }
-    }
     IRB_STAMP(a, 1);
     if (jb < je) {
-        if (bin == 0) mfma_chunk_run<true, FUSED ? 16 : 0>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
-        else          mfma_chunk_run<false, FUSED ? 16 : 0>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
+        if (bin == 0) mfma_chunk_run<true>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
+        else          mfma_chunk_run<false>(rx, rh, lane, x_elem0, jb, je, acc_r, acc_n, acc_i, a);
     }
     IRB_STAMP(a, 2);
     // ---- store: accumulator register v of lane (i, kq) is O[n = 4 kq + v][i], i.e. block 256 tile + 16 n + i of the call; through
@@ -497,24 +405,6 @@ __device__ __forceinline__ void cmac_mfma_body(const StepArgs &a, int S, int bid
     for (int v = 0; v < 4; v++) l_o[(kMfmaSeg * (4 * kq + v) + i) * kMfmaOS + wave] = make_float2(acc_r[v] - acc_n[v], bin == 0 ? acc_i[v] : acc_i[v] - acc_r[v] - acc_n[v]);
     __syncthreads();
     IRB_STAMP(a, 4);
-    if constexpr (FUSED) {
-        // 16 bytes per lane (two bins), write-through: the inverse-FFT workgroups of this launch read these rows
-        const int sb2 = tid % (kMfmaBins / 2), srow2 = tid / (kMfmaBins / 2);
-        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part + (size_t) s * part_T * splits * M, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < kMfmaTile / (kMfmaThreads / (kMfmaBins / 2)); it++) {
-            const int tl = srow2 + (kMfmaThreads / (kMfmaBins / 2)) * it, t = kMfmaTile * tile + tl;
-            if (t < a.T) {
-                const float2 v0 = l_o[tl * kMfmaOS + 2 * sb2], v1 = l_o[tl * kMfmaOS + 2 * sb2 + 1];
-                const v4f_t q = {v0.x, v0.y, v1.x, v1.y};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, q), rp,
-                                                       (unsigned) ((((size_t) (t - t_base) * splits + split) * M + b0 + 2 * sb2) * 8), 0, 16 /* sc1 */);
-            }
-        }
-        lc_publish(a, a.lc_nA + (second ? a.mf_wgs0 : 0) + wg);
-        IRB_STAMP(a, 7);
-        return;
-    }
     const int sbin = tid % kMfmaBins, srow = tid / kMfmaBins;
 #pragma unroll
     for (int it = 0; it < kMfmaTile / (kMfmaThreads / kMfmaBins); it++) {
@@ -527,13 +417,6 @@ __device__ __forceinline__ void cmac_mfma_body(const StepArgs &a, int S, int bid
         }
     }
     IRB_STAMP(a, 7);
-}
-
-template <int N>
-__global__ __launch_bounds__(kMfmaThreads) void k_cmac_mfma(StepArgs a)
-{
-    __shared__ float2 l_o[kMfmaTile * kMfmaOS];
-    cmac_mfma_body<N, false>(a, 0, (int) blockIdx.x, (int) gridDim.x, l_o);
 }
 
 }  // namespace irb

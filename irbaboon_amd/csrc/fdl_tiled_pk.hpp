@@ -324,18 +324,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_tile8_fused(StepArgs a)
 // blocks per workgroup: LDS = (NB + 1) * N * 4 + 3 N * 2 bytes must stay under the 64 KiB static limit
 template <int N> struct OlaGeom { static constexpr int NB = N <= 1024 ? 4 : N == 2048 ? 2 : 1; };
 
-// FUSED: part of k_long_call's grid (fdl_longcall.hpp, defined behind fdl_mfma.hpp) -- waits for the multiply workgroups of the
-// tile(s) its blocks lie in and sums their partial spectra with sc1 loads.
-__device__ __forceinline__ void lc_wait(const StepArgs &a, int f0, int n0, int f1, int n1);
-template <int N, int NB, bool FUSED>
-__device__ __forceinline__ void ifft_ola_run_body(const StepArgs &a, int S, int bid, float2 *l_tw, float2 (*l_buf)[N / 2])
+template <int N, int NB>
+__global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, int S)
 {
     constexpr int M = N / 2;
     constexpr int VPL = M > kWave ? M / kWave : 1;     // samples per lane of a half block (B <= M)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+    __shared__ float2 l_tw[TwLds<N>::SIZE];
+    __shared__ float2 l_buf[NB + 1][M];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     // this launch covers blocks [t_first, t_first + t_count) of the call (t_first a multiple of NB)
     const int runs = (a.t_count + NB - 1) / NB;
-    const int s = bid / runs, jb = a.t_first + (bid % runs) * NB;
+    const int s = blockIdx.x / runs, jb = a.t_first + (blockIdx.x % runs) * NB;
     const int j = jb - 1 + wave;                       // this wave's block
     const bool live = j < a.t_first + a.t_count && (j >= 0);
     const float scale = 1.0f / (float) N;
@@ -349,28 +348,10 @@ __device__ __forceinline__ void ifft_ola_run_body(const StepArgs &a, int S, int 
 #pragma unroll
         for (int i = 0; i < VPL; i++) ov[i] = o[min(lane + i * kWave, a.B - 1)];
     }
-    IRB_STAMP(a, 0);
-    if constexpr (FUSED) {
-        // the multiply workgroups of the tiles that hold blocks jb - 1 .. jb + NB - 1 (one tile, or two): all bin groups and splits
-        constexpr int GROUPS = M / 16;
-        const int t_lo = max(jb - 1, 0) / 256, t_hi = min(jb + NB - 1, a.T - 1) / 256;
-        auto words = [&](int tile, int &first, int &count) {
-            const bool second = a.mf_wgs0 > 0 && tile * 256 >= a.reg_t0[1];
-            const int tile_first = second ? a.mf2_tile_first : a.tile_first, tile_count = second ? a.mf2_tile_count : a.tile_count,
-                      splits = second ? a.mf2_splits : a.splits;
-            count = GROUPS * splits;
-            first = a.lc_nA + (second ? a.mf_wgs0 : 0) + count * ((tile - tile_first) + tile_count * s);
-        };
-        int f0, n0, f1 = 0, n1 = 0;
-        words(t_lo, f0, n0);
-        if (t_hi != t_lo) words(t_hi, f1, n1);
-        lc_wait(a, f0, n0, f1, n1);
-        IRB_STAMP(a, 1);
-    }
     if (live) {
         const int r = j >= a.reg_t0[1] ? 1 : 0;                                              // the region of block j (wave-uniform)
         const int nq = a.reg_nq[r];
-        wave_sum_rows<N, FUSED>(a.part + a.reg_off[r] + ((size_t) s * (a.reg_t0[r + 1] - a.reg_t0[r]) + (j - a.reg_t0[r])) * nq * M, nq, buf, lane);
+        wave_sum_rows<N>(a.part + a.reg_off[r] + ((size_t) s * (a.reg_t0[r + 1] - a.reg_t0[r]) + (j - a.reg_t0[r])) * nq * M, nq, buf, lane);
     }
     tws.store(l_tw);
     __syncthreads();
@@ -385,7 +366,6 @@ __device__ __forceinline__ void ifft_ola_run_body(const StepArgs &a, int S, int 
         }
     }
     __syncthreads();
-    IRB_STAMP(a, 7);                                          // (diagnostic builds: thread 0 stamps behind the last transform of the workgroup)
     if (!live) return;
     const float *y = reinterpret_cast<const float *>(buf);
     if (wave >= 1) {
@@ -425,14 +405,6 @@ __device__ __forceinline__ void ifft_ola_run_body(const StepArgs &a, int S, int 
             }
         }
     }
-}
-
-template <int N, int NB>
-__global__ __launch_bounds__(kWave * (NB + 1)) void k_ifft_ola_run(StepArgs a, int S)
-{
-    __shared__ float2 l_tw[TwLds<N>::SIZE];
-    __shared__ float2 l_buf[NB + 1][N / 2];
-    ifft_ola_run_body<N, NB, false>(a, S, (int) blockIdx.x, l_tw, l_buf);
 }
 
 }  // namespace irb

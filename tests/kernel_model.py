@@ -288,7 +288,7 @@ def mfma_layouts(X, H, T, P):
     return xt, ht, hist
 
 
-def mfma_wave(xt, ht, hist, tile, jb, je, touched=None):
+def mfma_wave(xt, ht, hist, tile, jb, je):
     """mfma_chunk_run for one wave (one bin of one tile, chunks [jb, je)): byte offsets of the buffer loads (per-lane voffset, scalar
     offset, immediate), which lanes load (the taps: lanes 0 .. 30, one 8-byte load; a chunk's new segment of blocks: the four lanes
     n = 0, two 16-byte loads: four real parts, four imaginary parts), ds_bpermute handing the taps to the lanes that multiply with
@@ -305,8 +305,6 @@ def mfma_wave(xt, ht, hist, tile, jb, je, touched=None):
 
     def ld32(byte):                                                 # two buffer_load_dwordx4: re of the lane's four k groups, then im
         assert byte % 16 == 0 and 0 <= byte // 4 and byte // 4 + 8 <= len(xt)
-        if touched is not None:
-            touched.add(byte // 8 // 16)                            # the 16-block segment (= 128-byte line) of Xt the load addresses
         f = xt[byte // 4: byte // 4 + 8]
         return list(f[:4]), list(f[4:])
 
@@ -427,104 +425,3 @@ def mfma_one_grid_decode(block_idx, grid, plan, S, groups):
     return (1 if second else 0, wg // (groups * splits * tile_count), tile_first + (wg // (groups * splits)) % tile_count,
             (wg // groups) % splits, wg % groups)
 
-
-
-LC_OLA_BLOCKS = 15
-
-
-def long_call_handoffs(S, T, P, M, nps=None, hist=False, wgs=256):
-    """k_long_call (fdl_longcall.hpp): forward FFTs, multiply and inverse FFTs of a matrix-core call as three regions of ONE grid.
-    Restates the index arithmetic of the hand-off -- which word a workgroup publishes (lc_publish), which words a workgroup of a
-    later region polls (the lc_wait calls in cmac_mfma_body / ifft_ola_run_body) -- and checks it against what the workgroups READ:
-    every Xt segment a multiply workgroup addresses (taken from mfma_wave's own loads, run-ahead loads included) and every
-    partial-spectrum row an inverse-FFT workgroup sums was written by a workgroup whose word is among those it waited for, and every
-    word it waits for belongs to a workgroup of LOWER index (dispatch order: no co-residency needed).  nps[s] = partitions in use of
-    stream s (default P).  Returns (nA, nB, nC)."""
-    groups_bins = M // 16
-    nps = [P] * S if nps is None else nps
-    groups = (T + 15) // 16
-    hist_len = mfma_hist(P)
-    BY = max(1, M // 64)
-    hist_wgs = (hist_len // 16) * BY                                # per stream
-    nA = S * groups + (S * hist_wgs if hist else 0)
-    plan = mfma_plan(T, S * groups_bins, P, wgs)
-    wgs_of = lambda l: S * l[1] * l[2] * groups_bins
-    nB = sum(wgs_of(l) for l in plan)
-    wgs0 = wgs_of(plan[0]) if len(plan) == 2 else 0
-    reg_t0 = [l[0] * MFMA_TILE for l in plan] + [T] * (3 - len(plan))
-    nC = S * ((T + LC_OLA_BLOCKS - 1) // LC_OLA_BLOCKS)
-
-    # region A: who writes which segment of Xt.  key (stream, bin, segment relative to the call's first block)
-    xt_writer = {}
-    for bid in range(S * groups):
-        s, g = bid // groups, bid % groups
-        for b in range(M):
-            xt_writer[(s, b, g)] = bid                              # its own blocks and the zeros behind the call's last one: ONE segment
-    if hist:
-        for w in range(S * hist_wgs):
-            seg, by, s = w % (hist_len // 16), (w // (hist_len // 16)) % BY, w // ((hist_len // 16) * BY)
-            for b in range(64 * by, min(M, 64 * by + 64)):
-                xt_writer[(s, b, seg - hist_len // 16)] = S * groups + w
-    # region B
-    Tpad = (T + MFMA_TILE - 1) // MFMA_TILE * MFMA_TILE
-    xt_dummy, ht_dummy = np.zeros(2 * (hist_len + Tpad)), np.zeros(mfma_taps(P), np.complex128)
-    part_writer, published = {}, set()
-    touched_cache = {}
-    for bid in range(nB):
-        second = len(plan) == 2 and bid >= wgs0
-        tile_first, tile_count, splits = plan[1] if second else plan[0]
-        wg = xcd_contiguous(bid - wgs0, nB - wgs0) if second else xcd_contiguous(bid, wgs0 if len(plan) == 2 else nB)
-        bg, split, tile, s = wg % groups_bins, (wg // groups_bins) % splits, tile_first + (wg // (groups_bins * splits)) % tile_count, wg // (groups_bins * splits * tile_count)
-        assert (1 if second else 0, s, tile, split, bg) == mfma_one_grid_decode(bid, nB, plan, S, groups_bins)
-        J = mfma_chunks(nps[s])
-        jb, je = J * split // splits, J * (split + 1) // splits
-        waits = set()
-        if jb < je:                                                  # cmac_mfma_body's lc_wait
-            g_lo = 16 * tile - je - 2
-            g0, g1 = max(g_lo, 0), min(16 * tile - jb + 16, groups)
-            waits |= set(range(s * groups + g0, s * groups + g1))
-            if g_lo < 0 and hist:
-                waits |= set(range(S * groups + s * hist_wgs, S * groups + (s + 1) * hist_wgs))
-            key = (tile, jb, je)
-            if key not in touched_cache:
-                t = set()
-                mfma_wave(xt_dummy, ht_dummy, hist_len, tile, jb, je, touched=t)
-                touched_cache[key] = t
-            for seg_abs in touched_cache[key]:                       # absolute segment of the Xt row -> relative to the call
-                seg = seg_abs - hist_len // 16
-                for b in range(16 * bg, 16 * bg + 16):
-                    w = xt_writer.get((s, b, seg))
-                    if w is not None:
-                        assert w in waits, ("multiply workgroup reads a segment it did not wait for", bid, s, tile, split, bg, seg)
-                    else:
-                        assert seg >= groups or (seg < 0 and not hist)      # nobody writes it in this launch
-        assert all(w < nA for w in waits)
-        word = nA + (wgs0 if second else 0) + wg
-        assert word not in published and nA <= word < nA + nB
-        published.add(word)
-        for t in range(MFMA_TILE * tile, min(T, MFMA_TILE * tile + MFMA_TILE)):
-            for b in range(16 * bg, 16 * bg + 16):
-                part_writer[(1 if second else 0, s, t, split, b)] = word
-    assert len(published) == nB
-    # region C
-    for bid in range(nC):
-        runs = (T + LC_OLA_BLOCKS - 1) // LC_OLA_BLOCKS
-        s, jb = bid // runs, (bid % runs) * LC_OLA_BLOCKS
-        t_lo, t_hi = max(jb - 1, 0) // 256, min(jb + LC_OLA_BLOCKS - 1, T - 1) // 256
-        waits = set()
-        for tile in {t_lo, t_hi}:                                    # ifft_ola_run_body's `words`
-            second = wgs0 > 0 and tile * 256 >= reg_t0[1]
-            tile_first, tile_count, splits = plan[1] if second else plan[0]
-            count = groups_bins * splits
-            first = nA + (wgs0 if second else 0) + count * ((tile - tile_first) + tile_count * s)
-            waits |= set(range(first, first + count))
-        assert all(nA <= w < nA + nB for w in waits)
-        for wave in range(LC_OLA_BLOCKS + 1):
-            j = jb - 1 + wave
-            if not (0 <= j < T):
-                continue
-            r = 1 if j >= reg_t0[1] else 0
-            for q in range(plan[r][2]):
-                for b in range(M):
-                    assert part_writer[(r, s, j, q, b)] in waits, ("inverse-FFT workgroup sums a row it did not wait for", bid, j, q, b)
-    return nA, nB, nC

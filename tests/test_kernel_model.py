@@ -98,17 +98,3 @@ def test_one_grid_carries_both_regions(T, S, groups, P, wgs):
     want = {(r, s, t, q, g) for r, l in enumerate(plan) for s in range(S) for t in range(l[0], l[0] + l[1]) for q in range(l[2]) for g in range(groups)}
     assert set(seen) == want
 
-
-
-@pytest.mark.parametrize("S,T,P,M,hist,wgs,nps", [(1, 3750, 375, 256, False, 256, None), (1, 1024, 375, 256, True, 256, None),
-                                                   (2, 2048, 3750, 64, False, 256, None), (1, 1280, 100, 16, True, 8, None),
-                                                   (3, 600, 40, 32, True, 256, [40, 1, 17]), (1, 4125, 375, 256, True, 256, None),
-                                                   (2, 300, 7, 128, True, 64, [0, 7])],
-                         ids=lambda v: str(v))
-def test_one_grid_long_call_handoffs(S, T, P, M, hist, wgs, nps):
-    """fdl_longcall.hpp / fdl_mfma.hpp (lc_publish, lc_wait): what every workgroup of k_long_call's later regions waits for covers what
-    it reads, and only workgroups of lower index -- configs[1]'s call (one region of 240 workgroups), a continuing call, configs[2]'s
-    geometry, a two-region plan, streams with fewer partitions in use than the handle's maximum (their splits may be empty)."""
-    from kernel_model import long_call_handoffs
-    nA, nB, nC = long_call_handoffs(S, T, P, M, nps, hist, wgs)
-    assert nA >= S * ((T + 15) // 16) and nB >= S * ((T + 255) // 256) * (M // 16) and nC == S * ((T + 14) // 15)
