@@ -663,32 +663,27 @@ def main():
 
     for k in range(W):
         step(k)
-    # The timed region: exactly K steps between barrier + device synchronisation on both sides.  On one GPU the host wall clock and
-    # the device's own events around the same K launches agree to ~0.1 %; a pass in which the wall clock exceeds the device time by
-    # more than 5 % had a host hiccup inside it (a descheduled thread on a shared box) and is timed again, at most twice -- the
-    # line says how many passes were timed, and reports the last one whatever it looks like.
-    timed_passes = 0
-    while True:
-        sync_all()
-        t0 = time.perf_counter()
-        for eng, _ in engines:
-            eng.mark(0)
-        for k in range(K):
-            step(W + k)
-        for eng, _ in engines:
-            eng.mark(1)
-        sync_all()
-        wall = time.perf_counter() - t0
-        timed_passes += 1
-        ev_ms = [eng.elapsed_ms() for eng, _ in engines]          # per device: its own K launches on its own stream
-        if ranks:
-            wall = ranks.max(wall)
-            ev_ms_max = ranks.max(max(ev_ms))
-            ev_ms_min = -ranks.max(-min(ev_ms))
-        else:
-            ev_ms_max, ev_ms_min = max(ev_ms), min(ev_ms)
-        if world > 1 or wall * 1e3 <= 1.05 * ev_ms_max or timed_passes >= 3:
-            break
+    # The timed region: exactly K steps between barrier + device synchronisation on both sides, timed ONCE (rounds 3-4 timed a pass
+    # again when the host wall clock exceeded the device's events by more than 5 % -- a best-of-three on the headline; removed in
+    # round 5: a host hiccup inside the region is reported as measured and flagged in the line).
+    sync_all()
+    t0 = time.perf_counter()
+    for eng, _ in engines:
+        eng.mark(0)
+    for k in range(K):
+        step(W + k)
+    for eng, _ in engines:
+        eng.mark(1)
+    sync_all()
+    wall = time.perf_counter() - t0
+    timed_passes = 1
+    ev_ms = [eng.elapsed_ms() for eng, _ in engines]          # per device: its own K launches on its own stream
+    if ranks:
+        wall = ranks.max(wall)
+        ev_ms_max = ranks.max(max(ev_ms))
+        ev_ms_min = -ranks.max(-min(ev_ms))
+    else:
+        ev_ms_max, ev_ms_min = max(ev_ms), min(ev_ms)
 
     total_samples = float(I) * world * B * K
     # `value`: all ranks' samples over the host wall clock around the K timed steps, bracketed by barrier + device synchronisation on both
@@ -698,7 +693,7 @@ def main():
     value = total_samples / wall / 1e6
     host_overhead = bool(world == 1 and wall * 1e3 > 1.05 * ev_ms_max)
     if host_overhead:
-        print(f"bench.py: host wall clock {wall * 1e3:.3f} ms exceeds the device's event time {ev_ms_max:.3f} ms by more than 5 % in {timed_passes} passes: "
+        print(f"bench.py: host wall clock {wall * 1e3:.3f} ms exceeds the device's event time {ev_ms_max:.3f} ms by more than 5 %: "
               "reported as measured (`value` follows the wall clock)", file=sys.stderr)
     launches_per_step = 1
     kern_ms = ev_ms_max / K           # fused path: one k_step_fused launch per step; the slowest device
