@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r04_bench.json, copied from a real MI355X run) keeps the driver's
+"""The committed bench line (profiles/r05_bench.json, copied from a real MI355X run) keeps the driver's
 contract: required keys, types, and internal consistency of the roofline / cpu_baseline objects."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "n_gpus_visible", "steps", "warmup", "ms_per_step", "ms_per_step_device_events", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores", "parity_spot", "pcie_inclusive",
               "environment", "setup_s_per_device"):
@@ -39,18 +39,24 @@ def test_committed_bench_line_follows_contract():
     assert "-march=native" in c["cflags"]
     chain = d["other_configs"]["configs[4]_2^20_deconvolve_chain"]
     assert chain["samples"] == 1 << 20 and chain["deconvolve_default_3x_smoothing_ms"] > chain["deconvolve_no_smoothing_ms"] > 0
-    # the drop-in function itself (host buffers in, host buffers out), with its breakdown and the oracle's time beside it
+    # the drop-in function itself (host buffers in, host buffers out) in its DEFAULT form -- pageable
+    # buffers through the library's pinned staging, nothing registered -- with its breakdown, the direct form on irb_host_alloc buffers
+    # beside it and the oracle's time
     for name, limit_ms in (("configs[0]_one_shot", 0.30), ("configs[1]_one_shot", 0.40)):
         e = d["other_configs"][name]
+        assert e["form"].startswith("staged")
         assert 0 < e["wall_ms_c_abi_min"] <= e["wall_ms_c_abi"] <= limit_ms and e["wall_ms_python_mirror"] <= limit_ms + 0.05
         b = e["breakdown_ms"]
-        assert b["direct"] == 1 and b["mac_on_matrix_cores"] == 1 and b["pieces"] == 1 and b["steps"] <= b["blocks_per_chunk"]
-        assert 0 < b["fft_in_ms"] and 0 < b["mac_ms"] and 0 < b["fft_out_ms"] and b["fft_in_ms"] + b["mac_ms"] + b["fft_out_ms"] <= b["device_ms"] * 1.02 <= b["total_ms"] * 1.02
+        assert b["direct"] == 0 and b["registered_ranges"] == 0 and b["threads"] >= 1
+        assert b["mac_on_matrix_cores"] == 1 and b["pieces"] == 1 and b["chunks"] >= 1 and b["in_chunks"] == 1
+        assert 0 < b["fft_in_ms"] and 0 < b["mac_ms"] and 0 < b["fft_out_ms"] and b["device_ms"] <= b["total_ms"] * 1.02
+        p = e["direct_pinned"]
+        assert p["breakdown_ms"]["direct"] == 1 and p["breakdown_ms"]["registered_ranges"] == 0 and 0 < p["wall_ms_c_abi"] <= e["wall_ms_c_abi"]
         assert e["cpu_oracle_ms_1_core"] > 20 * e["wall_ms_c_abi"]
-    e2 = d["other_configs"]["configs[2]_one_shot"]                           # 18750 steps: two multiplies, the FDL carried between them
-    assert e2["breakdown_ms"]["direct"] == 1 and e2["breakdown_ms"]["pieces"] == 2 and 0 < e2["wall_ms_c_abi"] < 6.0
+    e2 = d["other_configs"]["configs[2]_one_shot"]                           # 18750 steps: several pieces, the FDL carried between them
+    assert e2["breakdown_ms"]["direct"] == 0 and e2["breakdown_ms"]["pieces"] >= 2 and 0 < e2["wall_ms_c_abi"] < 6.0
     enp = d["other_configs"]["configs[1]_nonperiodic_one_shot"]             # convolveNonPeriodic, one 2^21-point transform per signal
-    assert enp["fft_len"] == 1 << 21 and 0 < enp["wall_ms_c_abi_min"] <= enp["wall_ms_c_abi"] < 0.6 and enp["cpu_oracle_ms_1_core"] > 100 * enp["wall_ms_c_abi"]
+    assert enp["fft_len"] == 1 << 21 and 0 < enp["wall_ms_c_abi_min"] <= enp["wall_ms_c_abi"] < 0.8 and enp["cpu_oracle_ms_1_core"] > 100 * enp["wall_ms_c_abi"]
     raw = d["other_configs"]["configs[1]_ir_spectra_raw"]                    # IRtoRealFFTRaw without an engine per call
     assert raw["rows"] == 376 and raw["floats_per_row"] == 512 and 0 < raw["wall_ms_python_mirror"] < 1.0
     assert d["other_configs"]["configs[1]_offline_one_stream"]["mac_kernel"] == "k_cmac_mfma"
@@ -71,14 +77,17 @@ def test_committed_bench_line_follows_contract():
         else:                                                              # time-tiled: flops against the fp32 vector peak, no GB/s figure
             assert "algorithmic_GBps" not in e and "algorithmic_GBps_streaming_model" not in e
             assert abs(e["TFLOPs"] - e["fp32_flops"] / (e["ms_per_call"] * 1e-3) / 1e12) / e["TFLOPs"] < 2e-2
-            assert abs(e["frac_of_157.3"] - e["TFLOPs"] / 157.3) < 1e-3 and e["frac_of_157.3"] < 1.0
+            # (the fraction says what it is a fraction of: eight flop per complex product, whatever the kernel executes)
+            assert abs(e["frac_algorithmic_4product"] - e["TFLOPs"] / 157.3) < 1e-3 and e["frac_algorithmic_4product"] < 1.0
+            if e["mac_kernel"] == "k_cmac_mfma":
+                assert 0 < e["frac_executed_mfma"] < e["frac_algorithmic_4product"] and e["executed_mfma_flops"] < e["fp32_flops"]
             assert 0 < e["frac_of_hbm_peak_min_traffic"] < 1.0
 
 
 def test_every_bench_kernel_is_launched_by_a_parity_test():
-    """profiles/r04_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
-    (profiles/collect_r04.py): no kernel is timed that the parity suite does not also run."""
-    lines = open(os.path.join(ROOT, "profiles", "r04_kernel_coverage.txt")).read().strip().splitlines()
+    """profiles/r05_kernel_coverage.txt joins the rocprofv3 kernel traces of `python bench.py` and `pytest -m gpu`
+    (profiles/collect_r05.py): no kernel is timed that the parity suite does not also run."""
+    lines = open(os.path.join(ROOT, "profiles", "r05_kernel_coverage.txt")).read().strip().splitlines()
     assert lines[-1] == "bench kernels without a parity-test launch: 0"
     rows = [l for l in lines[1:-1] if "irb::" in l]
     assert len(rows) >= 20 and not any("NOT RUN" in l for l in rows)
