@@ -204,7 +204,7 @@ int  irb_fdl_download(irb_fdl *h, float *dst, const float *d_src, size_t n_float
  * `out` must not overlap `audio` (the reference returns a new buffer; IRB_ERR_ARG otherwise).
  * How the samples reach the device.  Buffers in ordinary (pageable) memory -- a juce::AudioBuffer, a std::vector, a numpy array
  * -- are NEVER made device-visible: their samples pass through the library's own pinned staging ("staged form": chunks packed by
- * up to IRB_OFFLINE_THREADS host threads, default 3 with the caller, while the device already transforms the chunks before).
+ * up to IRB_OFFLINE_THREADS host threads, default 5 with the caller, while the device already transforms the chunks before).
  * When audio AND out are HIP host memory already (irb_host_alloc, hipHostMalloc, or registered by the caller itself) the kernels
  * read and write them in place ("direct form", no host copy); the same for the impulse response on its own.
  * IRB_OFFLINE_DIRECT=1 opts in to registering pageable buffers with the runtime for the duration of the call (the round-4

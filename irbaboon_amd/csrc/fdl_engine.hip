@@ -1872,7 +1872,11 @@ int irb_convolve_periodic(int device, const float *const *audio, int audio_ch, i
     float *const dev_in = h->d_hio, *const dev_out = h->d_hio + (size_t) audio_ch * stride;
     int helpers = 0;
     if (!direct) {
-        const int want_threads = std::max(1, std::min(kCrewMax, env_int("IRB_OFFLINE_THREADS", 3)));
+        // default: 5 with the caller where the host has the cores (profiles/NOTES.md, round 5: configs[1] 0.311 / 0.301 / 0.295 / 0.289 / 0.292 ms
+        // with 2 / 3 / 4 / 5 / 6 threads, medians of five alternating passes on one box), never more than half of them
+        const int hw = (int) std::thread::hardware_concurrency();
+        const int dflt_threads = std::max(1, std::min(5, hw > 0 ? hw / 2 : 3));
+        const int want_threads = std::max(1, std::min(kCrewMax, env_int("IRB_OFFLINE_THREADS", dflt_threads)));
         const long call_bytes = (long) sizeof(float) * ((long) La + Lout) * audio_ch;
         // (a helper needs tens of microseconds to wake up: calls that move less than a megabyte are over before it would have copied anything)
         helpers = (want_threads > 1 && call_bytes >= dbg_int("offline_helpers_from", 1 << 20)) ? g.crew.ensure(want_threads - 1) : 0;

@@ -2,7 +2,7 @@
 //
 // For users:
 //   IRB_OFFLINE_DIRECT      one-shot calls: unset / auto = zero-copy only for HIP host memory, 1 = also register pageable buffers, 0 = never
-//   IRB_OFFLINE_THREADS     host threads of a staged one-shot call, the caller included (default 3)
+//   IRB_OFFLINE_THREADS     host threads of a staged one-shot call, the caller included (default 5, at most half of the host's cores)
 //   IRB_RT_RESIDENT         0 = the plug-in adapter launches one kernel per callback instead of keeping a resident server
 //   IRB_RT_SERVER_IDLE_US   how long a resident server waits for the next callback before it leaves (default 20 000)
 //   IRB_RT_SERVER_LIFE_MS   the longest a resident server generation lives (default 250)

@@ -220,7 +220,7 @@ def test_one_shot_calls_never_register_pageable_memory_by_default(monkeypatch):
 
 
 def test_staged_pipeline_threads_and_chunking(monkeypatch):
-    """The staged form's host pipeline: any number of threads (the caller alone, the default three, more), helpers forced onto
+    """The staged form's host pipeline: any number of threads (the caller alone, three, five = the default, two), helpers forced onto
     calls too short to want them, the forward FFTs as ONE launch that waits for the packing threads' words (the default where the
     matrix cores multiply and blocks are whole cache lines) or launched chunk by chunk, items / chunks of 16 blocks (hundreds of
     words per piece, and more chunks than there are words: the chunk size doubles), several pieces on two streams -- every variant

@@ -3,7 +3,7 @@ from pageable host buffers, wall clock, with the library's own breakdown of the 
 usage: python tools/oneshot_probe.py [cfg0|cfg1|cfg2|all] [reps] [pinned]
 Default = the staged form (pageable numpy buffers through the library's pinned staging); `pinned` puts audio, IR and result into
 irb_host_alloc memory (direct form, nothing registered); IRB_OFFLINE_DIRECT=1 opts in to per-call registration of the pageable
-buffers.  IRB_OFFLINE_THREADS = host threads of the staged form (default 3).  Internal knobs: IRB_DEBUG="offline_chunk=..,
+buffers.  IRB_OFFLINE_THREADS = host threads of the staged form (default 5).  Internal knobs: IRB_DEBUG="offline_chunk=..,
 offline_max_blocks=..,offline_helpers_from=..,offline_pieces=..(how many pieces a long signal is cut into at most, default 2)"."""
 import ctypes as C
 import os
