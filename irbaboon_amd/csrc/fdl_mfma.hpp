@@ -127,7 +127,12 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
     if ((int) blockIdx.x >= S * groups) {
         // extra workgroups of a call that continues a stream (a.hist_first >= 0): the xt_hist blocks before the call's first one go
         // from the FDL ring into Xt's history columns (k_rows_to_columns' transpose, plus the segment permutation), 16 ring
-        // rows x 64 bins per workgroup through LDS
+        // rows x 64 bins per workgroup through LDS.
+        // (xt_hist = 16 (J + 3) reaches further back than the ring keeps apart from this call's own rows when the call is within
+        // xt_hist - Ppad - 8 blocks of the handle's longest: the oldest history rows would share ring slots with blocks the other
+        // workgroups of this launch are writing.  Those rows are more than R - T >= Ppad + 8 > np blocks old -- they only ever meet
+        // the zero taps behind the IR -- so they are not read at all: zeros go into their columns, and nothing of this call's own
+        // input, finite or not, can turn up in front of it.)
         constexpr int BW = M < 64 ? M : 64, BY = M / BW;
         float2 (*l_t)[BW + 1] = reinterpret_cast<float2 (*)[BW + 1]>(&l_buf[0][0]);
         const int w = blockIdx.x - S * groups, r0 = (w % (a.xt_hist / 16)) * 16, b0 = ((w / (a.xt_hist / 16)) % BY) * BW, s = w / ((a.xt_hist / 16) * BY);
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(kWave * PushTGeom<N>::NBW) void k_push_fft_batch_t(
         float2 *dst = a.Xt + (size_t) s * M * a.xt_len;
         for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {
             const int r = e / BW, b = e % BW;
-            l_t[r][b] = src[(size_t) ((a.hist_first + r0 + r) % a.R) * M + b0 + b];
+            const bool own_row = a.xt_hist - (r0 + r) + a.T > a.R;          // its ring slot holds a block of THIS call
+            l_t[r][b] = own_row ? make_float2(0.f, 0.f) : src[(size_t) ((a.hist_first + r0 + r) % a.R) * M + b0 + b];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < 16 * BW; e += kWave * NBW) {

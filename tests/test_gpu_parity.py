@@ -1251,6 +1251,31 @@ def test_packed_fma_tiled_kernel(monkeypatch, I, C, B, Lh, T):
             assert rel_rms(outs[0][i * C + c], ref[c, :T * B]) < RMS_TOL
 
 
+def test_non_finite_sample_does_not_reach_back_through_the_history_rebuild(monkeypatch):
+    """A matrix-core call that CONTINUES a stream rebuilds Xt's history columns from the FDL ring, xt_hist = 16 (J + 3) blocks back --
+    further than the ring keeps apart from the call's own rows when the call is as long as the handle's longest.  Those oldest rows
+    (beyond the IR: zero taps only) must come out as zeros, not as whatever the other workgroups of the launch are writing into the
+    shared slots: a NaN in block 250 of a 300-block call (np = 20, ring of 332 slots, history rows 0 .. 63 share slots with blocks
+    236 .. 299) must leave every output block before 250 - 31 exactly as in the clean run, every time."""
+    B, Lh, T, bad = 32, 20 * 32, 300, 250
+    x = white_noise(8800, 2 * T * B)[None].copy()
+    h = decaying_ir(8801, Lh)[None]
+    _dbg(monkeypatch, mfma_min_t=2)
+    with FdlEngine(1, 1, B, Lh, max_blocks_per_call=T) as eng:
+        eng.set_ir(0, h)
+        assert eng.mac_kernel_name(T) == "k_cmac_mfma"
+        eng.process(x[:, :T * B])
+        clean = eng.process(x[:, T * B:])[0].reshape(T, B)
+        xb = x.copy()
+        xb[0, (T + bad) * B + 3] = np.nan
+        for _ in range(20):                                # (the old overlap was a race that rarely went the wrong way -- this guards the rule, it did not catch the old code)
+            eng.reset()
+            eng.process(xb[:, :T * B])
+            y = eng.process(xb[:, T * B:])[0].reshape(T, B)
+            assert np.isfinite(y[:bad - 31]).all() and np.array_equal(y[:bad - 31], clean[:bad - 31])
+            assert not np.isfinite(y[bad:bad + 20]).any()
+
+
 @pytest.mark.parametrize("min_t", ["2", "0"], ids=["matrix_cores", "packed_fma"])
 def test_non_finite_sample_stays_inside_the_documented_window(monkeypatch, min_t):
     """include/irb_fdl.h (irb_fdl_process): calls of several blocks multiply in tiles along the time axis whose zero padding meets
